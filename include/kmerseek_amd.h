@@ -1,0 +1,198 @@
+/*
+ * kmerseek_amd.h — C ABI of the MI355X (gfx950) protein k-mer sketch-and-search engine.
+ *
+ * This is the drop-in boundary for the one hot path of seanome/kmerseek:
+ *   sketch : sliding-window k-mer -> reduced-alphabet re-encode -> MurmurHash3_x64_128.h1 (seed 42)
+ *            -> FracMinHash keep-below-threshold -> per-sequence sorted unique hashes + abundances
+ *   search : sorted-hash set intersection of every query sketch against an index of target sketches
+ *
+ * The reference has no FFI seam of its own for this path (sourmash / branchwater are linked-in
+ * Rust crates).  Each entry point below names the reference interface it replaces; a Rust
+ * `extern "C"` block or a Python ctypes stub binds them 1:1.
+ *
+ * Conventions
+ *   - every function returns a ks_status (0 = ok) unless documented otherwise; nothing throws
+ *     or aborts across this boundary; ks_last_error(ctx) gives the message of the last failure.
+ *   - a ks_ctx owns one HIP device + one stream + a grow-only device workspace.  It is NOT
+ *     thread-safe: use one context per host thread (the reference's `&self` + rayon fan-out,
+ *     src/rust/index.rs:990-1005, becomes one batched call).
+ *   - inputs are caller-owned and only read during the call; outputs are library-owned opaque
+ *     objects, released with the matching *_free.  All calls are synchronous on return unless
+ *     the name ends in _async.
+ *   - there is no CPU fallback: without a HIP device ks_ctx_create fails with KS_ERR_NO_DEVICE.
+ */
+#ifndef KMERSEEK_AMD_H
+#define KMERSEEK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KS_ABI_VERSION 1
+
+typedef enum ks_status {
+    KS_OK = 0,
+    KS_ERR_INVALID_MOLTYPE = 1, /* IndexError::InvalidMoltype, src/rust/errors.rs:8-9; text of encoding.rs:22-25 */
+    KS_ERR_INVALID_KSIZE = 2,   /* IndexError::InvalidKsize, src/rust/errors.rs:20-21 */
+    KS_ERR_INVALID_RESIDUE = 3, /* IndexError::InvalidAminoAcid(char, pos), src/rust/errors.rs:14-15 */
+    KS_ERR_INVALID_ARG = 4,
+    KS_ERR_OOM = 5,
+    KS_ERR_HIP = 6,
+    KS_ERR_NO_DEVICE = 7,
+    KS_ERR_CAPACITY = 8,        /* a device-side list (hit pairs) outgrew its hard cap */
+    KS_ERR_INVALID_SCALED = 9
+} ks_status;
+
+/* get_hash_function_from_moltype / get_encoding_fn_from_moltype, src/rust/encoding.rs:17-53;
+ * PyProteinEncoding Raw/Dayhoff/HP, src/rust/lib.rs:29-65. */
+typedef enum ks_moltype { KS_PROTEIN = 0, KS_DAYHOFF = 1, KS_HP = 2 } ks_moltype;
+
+#define KS_SEED_DEFAULT 42ull /* pub const SEED, src/rust/signature.rs:12 */
+#define KS_MAX_KSIZE 128u
+
+/* KmerMinHash::new(scaled, 3*ksize, hashfn, seed, track_abundance=true, num=0),
+ * src/rust/signature.rs:120-131.  ksize is the PROTEIN k (the sourmash ksize is 3*ksize). */
+typedef struct ks_params {
+    uint32_t ksize;   /* 1..KS_MAX_KSIZE */
+    uint32_t scaled;  /* >= 1; max_hash as ks_max_hash() */
+    uint32_t moltype; /* ks_moltype */
+    uint32_t flags;   /* reserved, 0 */
+    uint64_t seed;    /* KS_SEED_DEFAULT */
+} ks_params;
+
+typedef struct ks_ctx ks_ctx;
+typedef struct ks_sketches ks_sketches; /* device-resident CSR: offsets[n+1], hashes u64, abund u32 */
+typedef struct ks_index ks_index;       /* device-resident inverted index: postings sorted by hash */
+typedef struct ks_hits ks_hits;         /* device-resident COO (qid, tid, intersect, n_weighted) */
+typedef struct ks_kmerpos ks_kmerpos;   /* device-resident (seq, start, hash) triples */
+
+/* ---- library / context ------------------------------------------------------------------ */
+
+uint32_t ks_abi_version(void);
+const char *ks_status_string(int status);
+
+/* "protein" | "raw" | "hp" | "dayhoff" -> ks_moltype (src/rust/encoding.rs:17-27).
+ * Returns KS_ERR_INVALID_MOLTYPE for anything else. */
+int ks_moltype_from_string(const char *name, uint32_t *moltype_out);
+
+/* sourmash max_hash_for_scaled as used by KmerMinHash::new (src/rust/signature.rs:124-131). */
+uint64_t ks_max_hash(uint32_t scaled);
+
+/* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
+ * to let the context create its own non-blocking stream. */
+int ks_ctx_create(int device, void *hip_stream, ks_ctx **out);
+void ks_ctx_destroy(ks_ctx *ctx);
+const char *ks_last_error(const ks_ctx *ctx);
+void *ks_ctx_stream(const ks_ctx *ctx); /* the hipStream_t all kernels are launched on */
+int ks_ctx_synchronize(ks_ctx *ctx);
+
+/* ---- host-side pre-step ------------------------------------------------------------------ */
+
+typedef struct ks_residue_error {
+    uint32_t seq_index; /* index of the offending record in the batch */
+    uint32_t position;  /* 1-based, in the OUTPUT so far (src/rust/aminoacid.rs:86) */
+    uint8_t residue;
+} ks_residue_error;
+
+/* AminoAcidAmbiguity::validate_and_resolve (src/rust/aminoacid.rs:74-105) on one record:
+ * accepts the 20 standard residues + X U O * + B Z J; truncates after the first '*' (inclusive);
+ * B->D|N, Z->E|Q, J->I|L chosen by a SplitMix64 stream seeded with rng_seed (the reference draws
+ * from rand::rng(), aminoacid.rs:48 — non-reproducible by construction).
+ * upper != 0 first upper-cases ASCII (the FASTA path, src/rust/index.rs:1000).
+ * out must hold len bytes.  Returns KS_OK or KS_ERR_INVALID_RESIDUE (err filled, seq_index = 0). */
+int ks_validate_and_resolve(const uint8_t *seq, uint64_t len, int upper, uint64_t rng_seed,
+                            uint8_t *out, uint64_t *out_len, ks_residue_error *err);
+
+/* ---- sketch ------------------------------------------------------------------------------- */
+
+/* Replaces the rayon loop of process_batch_parallel (src/rust/index.rs:984-1016) around
+ * ProteinSignature::add_protein -> sourmash KmerMinHash::add_protein (src/rust/signature.rs:273-282),
+ * and branchwater do_manysketch(singleton=True) (src/python/kmerseek/sketch.py:33-39).
+ *
+ * residues   : n_seqs sequences concatenated, 1 byte per residue (ASCII), HOST memory
+ * seq_offsets: n_seqs+1 ascending byte offsets into residues, HOST memory
+ * Residues are hashed as given after ASCII upper-casing (what sourmash does internally); run
+ * ks_validate_and_resolve first for the Rust-path semantics.
+ * Result: per sequence, ascending unique hashes h with 0 < h <= max_hash and abund = number of
+ * windows of that sequence hashing to h. */
+int ks_sketch_batch(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_offsets,
+                    uint32_t n_seqs, const ks_params *params, ks_sketches **out);
+
+/* Same, with residues / seq_offsets already resident in device memory (HBM) on ctx's device.
+ * n_residues = seq_offsets[n_seqs]; max_seq_len >= the longest sequence (0 = let the library
+ * compute it, which costs one device->host sync). */
+int ks_sketch_batch_device(ks_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_seq_offsets,
+                           uint32_t n_seqs, uint64_t n_residues, uint32_t max_seq_len,
+                           const ks_params *params, ks_sketches **out);
+
+uint32_t ks_sketches_n_seqs(const ks_sketches *s);
+uint64_t ks_sketches_n_hashes(const ks_sketches *s);
+uint64_t ks_sketches_n_windows(const ks_sketches *s); /* k-mer windows hashed to build it */
+void ks_sketches_params(const ks_sketches *s, ks_params *out);
+/* device pointers (valid until ks_sketches_free): offsets u64[n+1], hashes u64[], abund u32[] */
+const uint64_t *ks_sketches_device_offsets(const ks_sketches *s);
+const uint64_t *ks_sketches_device_hashes(const ks_sketches *s);
+const uint32_t *ks_sketches_device_abunds(const ks_sketches *s);
+/* any of the three host pointers may be NULL */
+int ks_sketches_copy_to_host(ks_ctx *ctx, const ks_sketches *s, uint64_t *offsets,
+                             uint64_t *hashes, uint32_t *abunds);
+/* upload an existing CSR (e.g. sketches loaded from a .sig.zip) so it can be indexed / searched */
+int ks_sketches_from_host(ks_ctx *ctx, const uint64_t *offsets, const uint64_t *hashes,
+                          const uint32_t *abunds, uint32_t n_seqs, const ks_params *params,
+                          ks_sketches **out);
+void ks_sketches_free(ks_sketches *s);
+
+/* ---- k-mer positions ----------------------------------------------------------------------- */
+
+/* Replaces ProteomeIndex::process_kmers (src/rust/index.rs:749-786): for every window whose hash
+ * is in the sequence's sketch emit (seq, start, hash), ordered by (seq, start).  With the
+ * FracMinHash rule "in the sketch" == "0 < h <= max_hash", so no membership scan is needed.
+ * The host groups triples into KmerInfo{encoded_kmer, original_kmer -> [positions]} (src/rust/kmer.rs:6-12). */
+int ks_kmer_positions(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_offsets,
+                      uint32_t n_seqs, const ks_params *params, ks_kmerpos **out);
+uint64_t ks_kmerpos_count(const ks_kmerpos *p);
+int ks_kmerpos_copy_to_host(ks_ctx *ctx, const ks_kmerpos *p, uint32_t *seq, uint32_t *start,
+                            uint64_t *hash);
+void ks_kmerpos_free(ks_kmerpos *p);
+
+/* ---- index + search ------------------------------------------------------------------------ */
+
+/* Builds the inverted index over target sketches: postings (hash, tid, abund) sorted by hash.
+ * Stands where `kmerseek index` / do_index builds its search structure (src/python/kmerseek/index.py:55-74);
+ * the targets' per-sequence sizes and abundance totals are kept for the ratio columns. */
+int ks_index_build(ks_ctx *ctx, const ks_sketches *targets, ks_index **out);
+uint32_t ks_index_n_targets(const ks_index *ix);
+uint64_t ks_index_n_postings(const ks_index *ix);
+void ks_index_free(ks_index *ix);
+
+/* Replaces branchwater do_manysearch(threshold=0, output_all=False) (src/python/kmerseek/search.py:125-141):
+ * for every (query, target) pair with at least one shared hash emits
+ *   qid, tid, intersect = |mins_q ∩ mins_t|, n_weighted = Σ target abundance over the shared hashes,
+ * sorted by (qid, tid).  Pair results are identical to a pairwise sorted merge of the sketches. */
+int ks_search(ks_ctx *ctx, const ks_index *index, const ks_sketches *queries, ks_hits **out);
+uint64_t ks_hits_count(const ks_hits *h);
+uint64_t ks_hits_n_pair_instances(const ks_hits *h); /* Σ_h q(h)·t(h): matched (posting, posting) pairs */
+int ks_hits_copy_to_host(ks_ctx *ctx, const ks_hits *h, uint32_t *qid, uint32_t *tid,
+                         uint32_t *intersect, uint64_t *n_weighted);
+void ks_hits_free(ks_hits *h);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+
+/* Per-kernel HIP-event timing on ctx's stream (events bracket every launch while enabled). */
+typedef struct ks_kernel_time {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+} ks_kernel_time;
+int ks_timing_enable(ks_ctx *ctx, int enable);
+int ks_timing_reset(ks_ctx *ctx);
+/* resolves pending events (synchronizes the stream) and copies up to cap rows; *n = rows available */
+int ks_timing_get(ks_ctx *ctx, ks_kernel_time *rows, uint32_t cap, uint32_t *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMERSEEK_AMD_H */

@@ -1,0 +1,304 @@
+// ks_api.hip — the extern "C" entry points of include/kmerseek_amd.h that move data across the
+// boundary (host buffers <-> HBM) and own the opaque result objects, plus the k-mer position kernel.
+#include "ks_device.h"
+
+// ---------------------------------------------------------------------------------------------
+// sketches
+// ---------------------------------------------------------------------------------------------
+extern "C" int ks_sketch_batch_device(ks_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_seq_offsets,
+                                      uint32_t n_seqs, uint64_t n_residues, uint32_t max_seq_len,
+                                      const ks_params *params, ks_sketches **out) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (!out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, params, out);
+}
+
+static int upload_batch(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_offsets, uint32_t n_seqs,
+                        u8 **d_res, u64 **d_offs, u64 *n_res, u32 *max_len) {
+    if (!seq_offsets) return ks_fail(ctx, KS_ERR_INVALID_ARG, "seq_offsets is NULL");
+    u64 total = seq_offsets[n_seqs];
+    u64 mx = 0;
+    for (u32 s = 0; s < n_seqs; s++) {
+        if (seq_offsets[s + 1] < seq_offsets[s]) return ks_fail(ctx, KS_ERR_INVALID_ARG, "seq_offsets must be ascending (record %u)", s);
+        u64 l = seq_offsets[s + 1] - seq_offsets[s];
+        mx = l > mx ? l : mx;
+    }
+    if (seq_offsets[0] != 0) return ks_fail(ctx, KS_ERR_INVALID_ARG, "seq_offsets[0] must be 0");
+    if (mx > 0xfffffff0ULL) return ks_fail(ctx, KS_ERR_INVALID_ARG, "sequence longer than 2^32 residues");
+    if (total && !residues) return ks_fail(ctx, KS_ERR_INVALID_ARG, "residues is NULL");
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    KS_TRY(ks_alloc(ctx, d_res, (size_t)total + 16));
+    KS_TRY(ks_alloc(ctx, d_offs, (size_t)n_seqs + 1));
+    if (total) KS_HIP(ctx, hipMemcpyAsync(*d_res, residues, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    KS_HIP(ctx, hipMemcpyAsync(*d_offs, seq_offsets, ((size_t)n_seqs + 1) * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    *n_res = total;
+    *max_len = (u32)mx;
+    return KS_OK;
+}
+
+extern "C" int ks_sketch_batch(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_offsets, uint32_t n_seqs,
+                               const ks_params *params, ks_sketches **out) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
+    KS_TRY(ks_check_params(ctx, params));
+    u8 *d_res = nullptr;
+    u64 *d_offs = nullptr;
+    u64 n_res = 0;
+    u32 max_len = 0;
+    int st = upload_batch(ctx, residues, seq_offsets, n_seqs, &d_res, &d_offs, &n_res, &max_len);
+    if (st == KS_OK) st = ks_sketch_device_impl(ctx, d_res, d_offs, n_seqs, n_res, max_len, params, out);
+    (void)hipStreamSynchronize(ctx->stream);
+    ks_pool_free(ctx, d_res);
+    ks_pool_free(ctx, d_offs);
+    return st;
+}
+
+extern "C" uint32_t ks_sketches_n_seqs(const ks_sketches *s) { return s ? s->n_seqs : 0; }
+extern "C" uint64_t ks_sketches_n_hashes(const ks_sketches *s) { return s ? s->n_hashes : 0; }
+extern "C" uint64_t ks_sketches_n_windows(const ks_sketches *s) { return s ? s->n_windows : 0; }
+extern "C" void ks_sketches_params(const ks_sketches *s, ks_params *out) { if (s && out) *out = s->params; }
+extern "C" const uint64_t *ks_sketches_device_offsets(const ks_sketches *s) { return s ? s->d_offsets : nullptr; }
+extern "C" const uint64_t *ks_sketches_device_hashes(const ks_sketches *s) { return s ? s->d_hashes : nullptr; }
+extern "C" const uint32_t *ks_sketches_device_abunds(const ks_sketches *s) { return s ? s->d_abunds : nullptr; }
+
+extern "C" int ks_sketches_copy_to_host(ks_ctx *ctx, const ks_sketches *s, uint64_t *offsets, uint64_t *hashes,
+                                        uint32_t *abunds) {
+    if (!ctx || !s) return KS_ERR_INVALID_ARG;
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    if (offsets) KS_HIP(ctx, hipMemcpyAsync(offsets, s->d_offsets, ((size_t)s->n_seqs + 1) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    if (hashes && s->n_hashes) KS_HIP(ctx, hipMemcpyAsync(hashes, s->d_hashes, (size_t)s->n_hashes * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    if (abunds && s->n_hashes) KS_HIP(ctx, hipMemcpyAsync(abunds, s->d_abunds, (size_t)s->n_hashes * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KS_OK;
+}
+
+extern "C" int ks_sketches_from_host(ks_ctx *ctx, const uint64_t *offsets, const uint64_t *hashes, const uint32_t *abunds,
+                                     uint32_t n_seqs, const ks_params *params, ks_sketches **out) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (!offsets || !out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    KS_TRY(ks_check_params(ctx, params));
+    if (offsets[0] != 0) return ks_fail(ctx, KS_ERR_INVALID_ARG, "offsets[0] must be 0");
+    const u64 n = offsets[n_seqs];
+    if (n && (!hashes || !abunds)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "hashes/abunds is NULL");
+    for (u32 s = 0; s < n_seqs; s++) {
+        if (offsets[s + 1] < offsets[s]) return ks_fail(ctx, KS_ERR_INVALID_ARG, "offsets must be ascending");
+        for (u64 j = offsets[s] + 1; j < offsets[s + 1]; j++)
+            if (hashes[j] <= hashes[j - 1]) return ks_fail(ctx, KS_ERR_INVALID_ARG, "sketch %u is not strictly ascending", s);
+    }
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    ks_sketches *S = new ks_sketches();
+    memset(S, 0, sizeof *S);
+    S->ctx = ctx; S->params = *params; S->n_seqs = n_seqs; S->n_hashes = n; S->n_windows = 0;
+    int st = ks_alloc(ctx, &S->d_offsets, (size_t)n_seqs + 1);
+    if (st == KS_OK) st = ks_alloc(ctx, &S->d_hashes, (size_t)n);
+    if (st == KS_OK) st = ks_alloc(ctx, &S->d_abunds, (size_t)n);
+    if (st != KS_OK) { ks_sketches_free(S); return st; }
+    hipError_t e = hipMemcpyAsync(S->d_offsets, offsets, ((size_t)n_seqs + 1) * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(S->d_hashes, hashes, (size_t)n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(S->d_abunds, abunds, (size_t)n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ks_sketches_free(S); return ks_fail(ctx, KS_ERR_HIP, "upload failed: %s", hipGetErrorString(e)); }
+    *out = S;
+    return KS_OK;
+}
+
+extern "C" void ks_sketches_free(ks_sketches *s) {
+    if (!s) return;
+    ks_pool_free(s->ctx, s->d_offsets);
+    ks_pool_free(s->ctx, s->d_hashes);
+    ks_pool_free(s->ctx, s->d_abunds);
+    delete s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-mer positions (ProteomeIndex::process_kmers, src/rust/index.rs:749-786)
+// One thread per residue position: sequence by binary search, window bytes through the LUT from
+// global memory, keep iff 0 < h <= max_hash and the window fits; order-preserving compaction by scan.
+// NOTE: the Rust path hashes the validated sequence as given (no upper-casing inside process_kmers);
+// inputs that reach it are already upper-case, so the LUT's case folding is unobservable.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_kmerpos_flag(const u8 *res, const u64 *offs, u32 n_seqs, u64 n_res, u32 k, u64 seed,
+                                                      u64 max_hash, const u8 *lut, u32 *flags, u64 *hash_tmp, u32 *seq_tmp) {
+    const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_res) return;
+    // sequence containing p: last s with offs[s] <= p
+    u32 lo = 0, hi = n_seqs;
+    while (lo < hi) {
+        u32 mid = lo + ((hi - lo) >> 1);
+        if (offs[mid + 1] > p) hi = mid; else lo = mid + 1;
+    }
+    u32 keep = 0;
+    u64 h = 0;
+    if (lo < n_seqs && p + k <= offs[lo + 1]) {
+        ks_murmur m;
+        m.init(seed);
+        const u8 *w = res + p;
+        const u32 nb = k >> 4, t = k & 15;
+        for (u32 b = 0; b < nb; b++) {
+            u64 k1 = 0, k2 = 0;
+            for (int i = 0; i < 8; i++) { k1 |= (u64)lut[w[16 * b + i]] << (8 * i); k2 |= (u64)lut[w[16 * b + 8 + i]] << (8 * i); }
+            m.block(k1, k2);
+        }
+        if (t) {
+            u64 k1 = 0, k2 = 0;
+            for (u32 i = 0; i < t && i < 8; i++) k1 |= (u64)lut[w[16 * nb + i]] << (8 * i);
+            for (u32 i = 8; i < t; i++) k2 |= (u64)lut[w[16 * nb + i]] << (8 * (i - 8));
+            m.tail(k1, k2, t);
+        }
+        h = m.finish((u64)k);
+        keep = (h != 0 && h <= max_hash) ? 1u : 0u;
+    }
+    flags[p] = keep;
+    hash_tmp[p] = h;
+    seq_tmp[p] = lo;
+}
+
+__global__ __launch_bounds__(256) void k_kmerpos_emit(const u32 *idx, const u64 *hash_tmp, const u32 *seq_tmp, const u64 *offs,
+                                                      u64 n_res, u64 max_hash, u32 *seq, u32 *start, u64 *hash) {
+    const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_res) return;
+    const u64 h = hash_tmp[p];
+    const u32 next = idx[p + 1];
+    if (next != idx[p]) { // kept
+        const u32 o = idx[p];
+        const u32 s = seq_tmp[p];
+        seq[o] = s;
+        start[o] = (u32)(p - offs[s]);
+        hash[o] = h;
+    }
+}
+
+int ks_kmerpos_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, const ks_params *p,
+                           ks_kmerpos **out) {
+    KS_TRY(ks_check_params(ctx, p));
+    if (n_res >= 0xfffffff0ULL) return ks_fail(ctx, KS_ERR_CAPACITY, "k-mer position batch limited to 2^32 residues");
+    ks_kmerpos *K = new ks_kmerpos();
+    memset(K, 0, sizeof *K);
+    K->ctx = ctx;
+    u32 *flags = nullptr, *seq_tmp = nullptr;
+    u64 *hash_tmp = nullptr;
+    int st = KS_OK;
+#define KP_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
+#define KP_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
+    if (n_res == 0 || n_seqs == 0) {
+        KP_CHECK(ks_alloc(ctx, &K->d_seq, 1)); KP_CHECK(ks_alloc(ctx, &K->d_start, 1)); KP_CHECK(ks_alloc(ctx, &K->d_hash, 1));
+        goto done;
+    }
+    {
+        KP_CHECK(ks_alloc(ctx, &flags, (size_t)n_res + 1));
+        KP_CHECK(ks_alloc(ctx, &seq_tmp, (size_t)n_res));
+        KP_CHECK(ks_alloc(ctx, &hash_tmp, (size_t)n_res));
+        const u32 grid = (u32)((n_res + 255) / 256);
+        const u64 max_hash = ks_max_hash(p->scaled);
+        ks_timer_begin(ctx, "kmerpos_flag");
+        hipLaunchKernelGGL(k_kmerpos_flag, dim3(grid), dim3(256), 0, ctx->stream, d_res, d_offs, n_seqs, n_res, p->ksize, p->seed,
+                           max_hash, (const u8 *)(ctx->d_lut + 256 * p->moltype), flags, hash_tmp, seq_tmp);
+        ks_timer_end(ctx);
+        KP_HIP(hipGetLastError());
+        // exclusive scan over n_res flags; flags[n_res] receives the total
+        KP_CHECK(ks_scan_u32_inplace(ctx, flags, n_res, flags + n_res));
+        KP_HIP(hipMemcpyAsync(ctx->h_pin, flags + n_res, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        KP_HIP(hipStreamSynchronize(ctx->stream));
+        K->n = *(u32 *)ctx->h_pin;
+        KP_CHECK(ks_alloc(ctx, &K->d_seq, (size_t)K->n)); KP_CHECK(ks_alloc(ctx, &K->d_start, (size_t)K->n));
+        KP_CHECK(ks_alloc(ctx, &K->d_hash, (size_t)K->n));
+        ks_timer_begin(ctx, "kmerpos_emit");
+        hipLaunchKernelGGL(k_kmerpos_emit, dim3(grid), dim3(256), 0, ctx->stream, (const u32 *)flags, (const u64 *)hash_tmp,
+                           (const u32 *)seq_tmp, d_offs, n_res, max_hash, K->d_seq, K->d_start, K->d_hash);
+        ks_timer_end(ctx);
+        KP_HIP(hipGetLastError());
+        KP_HIP(hipStreamSynchronize(ctx->stream));
+    }
+done:
+    ks_pool_free(ctx, flags); ks_pool_free(ctx, seq_tmp); ks_pool_free(ctx, hash_tmp);
+    if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_kmerpos_free(K); return st; }
+    *out = K;
+    return KS_OK;
+#undef KP_CHECK
+#undef KP_HIP
+}
+
+extern "C" int ks_kmer_positions(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_offsets, uint32_t n_seqs,
+                                 const ks_params *params, ks_kmerpos **out) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
+    KS_TRY(ks_check_params(ctx, params));
+    u8 *d_res = nullptr;
+    u64 *d_offs = nullptr;
+    u64 n_res = 0;
+    u32 max_len = 0;
+    int st = upload_batch(ctx, residues, seq_offsets, n_seqs, &d_res, &d_offs, &n_res, &max_len);
+    if (st == KS_OK) st = ks_kmerpos_device_impl(ctx, d_res, d_offs, n_seqs, n_res, params, out);
+    (void)hipStreamSynchronize(ctx->stream);
+    ks_pool_free(ctx, d_res);
+    ks_pool_free(ctx, d_offs);
+    return st;
+}
+
+extern "C" uint64_t ks_kmerpos_count(const ks_kmerpos *p) { return p ? p->n : 0; }
+
+extern "C" int ks_kmerpos_copy_to_host(ks_ctx *ctx, const ks_kmerpos *p, uint32_t *seq, uint32_t *start, uint64_t *hash) {
+    if (!ctx || !p) return KS_ERR_INVALID_ARG;
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    if (p->n) {
+        if (seq) KS_HIP(ctx, hipMemcpyAsync(seq, p->d_seq, (size_t)p->n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        if (start) KS_HIP(ctx, hipMemcpyAsync(start, p->d_start, (size_t)p->n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        if (hash) KS_HIP(ctx, hipMemcpyAsync(hash, p->d_hash, (size_t)p->n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KS_OK;
+}
+
+extern "C" void ks_kmerpos_free(ks_kmerpos *p) {
+    if (!p) return;
+    ks_pool_free(p->ctx, p->d_seq);
+    ks_pool_free(p->ctx, p->d_start);
+    ks_pool_free(p->ctx, p->d_hash);
+    delete p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// index + search
+// ---------------------------------------------------------------------------------------------
+extern "C" int ks_index_build(ks_ctx *ctx, const ks_sketches *targets, ks_index **out) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    return ks_index_build_impl(ctx, targets, out);
+}
+extern "C" uint32_t ks_index_n_targets(const ks_index *ix) { return ix ? ix->n_targets : 0; }
+extern "C" uint64_t ks_index_n_postings(const ks_index *ix) { return ix ? ix->n_postings : 0; }
+extern "C" void ks_index_free(ks_index *ix) {
+    if (!ix) return;
+    ks_pool_free(ix->ctx, ix->d_keys);
+    ks_pool_free(ix->ctx, ix->d_tids);
+    ks_pool_free(ix->ctx, ix->d_abunds);
+    delete ix;
+}
+
+extern "C" int ks_search(ks_ctx *ctx, const ks_index *index, const ks_sketches *queries, ks_hits **out) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    return ks_search_impl(ctx, index, queries, out);
+}
+extern "C" uint64_t ks_hits_count(const ks_hits *h) { return h ? h->n_hits : 0; }
+extern "C" uint64_t ks_hits_n_pair_instances(const ks_hits *h) { return h ? h->n_pair_instances : 0; }
+extern "C" int ks_hits_copy_to_host(ks_ctx *ctx, const ks_hits *h, uint32_t *qid, uint32_t *tid, uint32_t *intersect,
+                                    uint64_t *n_weighted) {
+    if (!ctx || !h) return KS_ERR_INVALID_ARG;
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)h->n_hits;
+    if (n) {
+        if (qid) KS_HIP(ctx, hipMemcpyAsync(qid, h->d_qid, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        if (tid) KS_HIP(ctx, hipMemcpyAsync(tid, h->d_tid, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        if (intersect) KS_HIP(ctx, hipMemcpyAsync(intersect, h->d_isect, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        if (n_weighted) KS_HIP(ctx, hipMemcpyAsync(n_weighted, h->d_nw, n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KS_OK;
+}
+extern "C" void ks_hits_free(ks_hits *h) {
+    if (!h) return;
+    ks_pool_free(h->ctx, h->d_qid);
+    ks_pool_free(h->ctx, h->d_tid);
+    ks_pool_free(h->ctx, h->d_isect);
+    ks_pool_free(h->ctx, h->d_nw);
+    delete h;
+}

@@ -1,0 +1,155 @@
+// ks_common.h — internal definitions shared by the HIP translation units of libkmerseek_amd.
+// gfx950 (MI355X) only: wave = 64 lanes, 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kmerseek_amd.h"
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+#define KS_WAVE 64
+
+// ---- device memory pool: grow-only, best-fit reuse, so steady-state batches never hipMalloc ----
+struct ks_pool_block {
+    void *ptr;
+    size_t size;
+    bool in_use;
+};
+
+struct ks_timer_slot {
+    hipEvent_t a, b;
+    int name_id;
+};
+
+struct ks_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cus = 256;
+    std::string err;
+    std::vector<ks_pool_block> pool;
+    // timing
+    bool timing = false;
+    std::vector<std::string> t_names;
+    std::vector<u64> t_launches;
+    std::vector<double> t_ms;
+    std::vector<ks_timer_slot> t_pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> t_free;
+    // small pinned host scratch for counters read back from the device
+    u64 *h_pin = nullptr; // 64 x u64
+    // encode LUTs (3 x 256 bytes) in device memory
+    u8 *d_lut = nullptr;
+};
+
+// returns nullptr and sets ctx->err on failure
+void *ks_pool_alloc(ks_ctx *ctx, size_t bytes);
+void ks_pool_free(ks_ctx *ctx, void *ptr);
+void ks_pool_trim(ks_ctx *ctx);
+
+int ks_fail(ks_ctx *ctx, int status, const char *fmt, ...);
+
+void ks_timer_begin(ks_ctx *ctx, const char *name);
+void ks_timer_end(ks_ctx *ctx);
+
+#define KS_HIP(ctx, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return ks_fail(ctx, KS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                           __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define KS_TRY(expr)                        \
+    do {                                    \
+        int s__ = (expr);                   \
+        if (s__ != KS_OK) return s__;       \
+    } while (0)
+
+// Launch on the context's stream, bracketed by HIP events when timing is enabled.
+#define KS_LAUNCH(ctx, name, kernel, grid, block, ...)                                   \
+    do {                                                                                 \
+        ks_timer_begin(ctx, name);                                                       \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__); \
+        ks_timer_end(ctx);                                                               \
+        KS_HIP(ctx, hipGetLastError());                                                  \
+    } while (0)
+
+template <typename T>
+static inline int ks_alloc(ks_ctx *ctx, T **out, size_t count) {
+    void *p = ks_pool_alloc(ctx, (count ? count : 1) * sizeof(T));
+    if (!p) return KS_ERR_OOM;
+    *out = (T *)p;
+    return KS_OK;
+}
+
+// ---- opaque objects ----
+struct ks_sketches {
+    ks_ctx *ctx;
+    ks_params params;
+    u32 n_seqs;
+    u64 n_hashes;
+    u64 n_windows;
+    u64 *d_offsets; // n_seqs + 1
+    u64 *d_hashes;  // n_hashes
+    u32 *d_abunds;  // n_hashes
+};
+
+struct ks_index {
+    ks_ctx *ctx;
+    ks_params params;
+    u32 n_targets;
+    u64 n_postings;
+    u64 *d_keys;   // sorted hashes
+    u32 *d_tids;   // target id per posting
+    u32 *d_abunds; // target abundance per posting
+};
+
+struct ks_hits {
+    ks_ctx *ctx;
+    u64 n_hits;
+    u64 n_pair_instances;
+    u32 *d_qid, *d_tid, *d_isect;
+    u64 *d_nw;
+};
+
+struct ks_kmerpos {
+    ks_ctx *ctx;
+    u64 n;
+    u32 *d_seq, *d_start;
+    u64 *d_hash;
+};
+
+// ---- device-wide primitives (ks_scan.hip, ks_sort.hip) ----
+// exclusive scan of n u32 values into u64 (out[n] = total is also written: out has n+1 entries)
+int ks_scan_u32_to_u64(ks_ctx *ctx, const u32 *in, u64 *out, u64 n);
+// exclusive scan u32 -> u32 in place (n < 2^32 total); optionally writes the total to d_total
+int ks_scan_u32_inplace(ks_ctx *ctx, u32 *data, u64 n, u32 *d_total);
+
+// LSD radix sort of (key u64, value V) on key bits [bit_lo, bit_hi), 8 bits per pass, stable.
+// Buffers ping-pong; on return *keys/*vals point at the sorted data (either input or alt).
+int ks_radix_sort_u32(ks_ctx *ctx, u64 **keys, u32 **vals, u64 *keys_alt, u32 *vals_alt, u64 n,
+                      int bit_lo, int bit_hi);
+int ks_radix_sort_u64(ks_ctx *ctx, u64 **keys, u64 **vals, u64 *keys_alt, u64 *vals_alt, u64 n,
+                      int bit_lo, int bit_hi);
+
+// ---- pipelines (ks_sketch.hip, ks_search.hip) ----
+int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,
+                          u32 max_seq_len, const ks_params *p, ks_sketches **out);
+int ks_kmerpos_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,
+                           const ks_params *p, ks_kmerpos **out);
+int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out);
+int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out);
+
+int ks_check_params(ks_ctx *ctx, const ks_params *p);

@@ -1,0 +1,305 @@
+// ks_ctx.hip — context, device memory pool, HIP-event timing, host-side helpers and the C-ABI
+// entry points that are pure plumbing.  No CPU fallback lives here: every compute entry point
+// ends in a HIP kernel launch (ks_sketch.hip / ks_search.hip).
+#include <cstdarg>
+#include <algorithm>
+
+#include "ks_common.h"
+
+// ---------------------------------------------------------------------------------------------
+int ks_fail(ks_ctx *ctx, int status, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return status;
+}
+
+extern "C" uint32_t ks_abi_version(void) { return KS_ABI_VERSION; }
+
+extern "C" const char *ks_status_string(int s) {
+    switch (s) {
+    case KS_OK: return "ok";
+    case KS_ERR_INVALID_MOLTYPE: return "invalid moltype";
+    case KS_ERR_INVALID_KSIZE: return "invalid k-mer size";
+    case KS_ERR_INVALID_RESIDUE: return "invalid amino acid";
+    case KS_ERR_INVALID_ARG: return "invalid argument";
+    case KS_ERR_OOM: return "out of device memory";
+    case KS_ERR_HIP: return "HIP runtime error";
+    case KS_ERR_NO_DEVICE: return "no HIP device";
+    case KS_ERR_CAPACITY: return "device list capacity exceeded";
+    case KS_ERR_INVALID_SCALED: return "invalid scaled";
+    default: return "unknown status";
+    }
+}
+
+// get_hash_function_from_moltype, src/rust/encoding.rs:17-27
+extern "C" int ks_moltype_from_string(const char *name, uint32_t *out) {
+    if (!name || !out) return KS_ERR_INVALID_ARG;
+    if (!strcmp(name, "protein") || !strcmp(name, "raw")) { *out = KS_PROTEIN; return KS_OK; }
+    if (!strcmp(name, "hp")) { *out = KS_HP; return KS_OK; }
+    if (!strcmp(name, "dayhoff")) { *out = KS_DAYHOFF; return KS_OK; }
+    return KS_ERR_INVALID_MOLTYPE;
+}
+
+// sourmash max_hash_for_scaled: (u64::MAX as f64 / scaled as f64) as u64, saturating
+extern "C" uint64_t ks_max_hash(uint32_t scaled) {
+    if (scaled == 0) return 0;
+    if (scaled == 1) return UINT64_MAX;
+    double v = 18446744073709551616.0 / (double)scaled;
+    if (v >= 18446744073709551616.0) return UINT64_MAX;
+    return (uint64_t)v;
+}
+
+int ks_check_params(ks_ctx *ctx, const ks_params *p) {
+    if (!p) return ks_fail(ctx, KS_ERR_INVALID_ARG, "params is NULL");
+    if (p->moltype > KS_HP)
+        return ks_fail(ctx, KS_ERR_INVALID_MOLTYPE,
+                       "Invalid moltype: %u, only 'protein', 'hp', or 'dayhoff' are supported", p->moltype);
+    if (p->ksize < 1 || p->ksize > KS_MAX_KSIZE)
+        return ks_fail(ctx, KS_ERR_INVALID_KSIZE, "Invalid k-mer size: %u", p->ksize);
+    if (p->scaled < 1) return ks_fail(ctx, KS_ERR_INVALID_SCALED, "Invalid scaled: %u", p->scaled);
+    return KS_OK;
+}
+
+// ---- encode LUTs: byte -> encoded byte of upper-cased residue --------------------------------
+// sourmash aa_to_dayhoff / aa_to_hp (selected at src/rust/encoding.rs:43-53); sourmash upper-cases
+// the sequence inside add_protein, so the LUT folds to_ascii_uppercase in.
+static void build_luts(u8 *lut) {
+    for (int m = 0; m < 3; m++)
+        for (int b = 0; b < 256; b++) {
+            u8 c = (b >= 'a' && b <= 'z') ? (u8)(b - 32) : (u8)b;
+            u8 e = c;
+            if (m == KS_DAYHOFF) {
+                switch (c) {
+                case 'C': e = 'a'; break;
+                case 'A': case 'G': case 'P': case 'S': case 'T': e = 'b'; break;
+                case 'D': case 'E': case 'N': case 'Q': e = 'c'; break;
+                case 'H': case 'K': case 'R': e = 'd'; break;
+                case 'I': case 'L': case 'M': case 'V': e = 'e'; break;
+                case 'F': case 'W': case 'Y': e = 'f'; break;
+                default: e = 'X';
+                }
+            } else if (m == KS_HP) {
+                switch (c) {
+                case 'A': case 'F': case 'G': case 'I': case 'L': case 'M': case 'P': case 'V':
+                case 'W': case 'Y': e = 'h'; break;
+                case 'N': case 'C': case 'S': case 'T': case 'D': case 'E': case 'R': case 'H':
+                case 'K': case 'Q': e = 'p'; break;
+                default: e = 'X';
+                }
+            }
+            lut[m * 256 + b] = e;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int ks_ctx_create(int device, void *hip_stream, ks_ctx **out) {
+    if (!out) return KS_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return KS_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return KS_ERR_INVALID_ARG;
+    ks_ctx *ctx = new ks_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
+        ctx->own_stream = true;
+    }
+    if (hipHostMalloc((void **)&ctx->h_pin, 64 * sizeof(u64)) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
+    if (hipMalloc((void **)&ctx->d_lut, 3 * 256) != hipSuccess) { delete ctx; return KS_ERR_OOM; }
+    u8 lut[768];
+    build_luts(lut);
+    if (hipMemcpy(ctx->d_lut, lut, sizeof lut, hipMemcpyHostToDevice) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
+    *out = ctx;
+    return KS_OK;
+}
+
+extern "C" void ks_ctx_destroy(ks_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->t_pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto &t : ctx->t_free) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
+    for (auto &b : ctx->pool) (void)hipFree(b.ptr);
+    if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" const char *ks_last_error(const ks_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+extern "C" void *ks_ctx_stream(const ks_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" int ks_ctx_synchronize(ks_ctx *ctx) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KS_OK;
+}
+
+// ---- pool ---------------------------------------------------------------------------------
+void *ks_pool_alloc(ks_ctx *ctx, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (size_t i = 0; i < ctx->pool.size(); i++) {
+        auto &b = ctx->pool[i];
+        if (!b.in_use && b.size >= bytes && b.size <= bytes * 2 + (1u << 20))
+            if (best < 0 || b.size < ctx->pool[best].size) best = (int)i;
+    }
+    if (best >= 0) { ctx->pool[best].in_use = true; return ctx->pool[best].ptr; }
+    size_t want = bytes < (1u << 20) ? bytes : ((bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1));
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { // give cached blocks back and retry once
+        ks_pool_trim(ctx);
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        ks_fail(ctx, KS_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return nullptr;
+    }
+    ctx->pool.push_back({p, want, true});
+    return p;
+}
+
+void ks_pool_free(ks_ctx *ctx, void *ptr) {
+    if (!ptr || !ctx) return;
+    for (auto &b : ctx->pool)
+        if (b.ptr == ptr) { b.in_use = false; return; }
+}
+
+void ks_pool_trim(ks_ctx *ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    std::vector<ks_pool_block> keep;
+    for (auto &b : ctx->pool) {
+        if (b.in_use) keep.push_back(b);
+        else (void)hipFree(b.ptr);
+    }
+    ctx->pool.swap(keep);
+}
+
+// ---- timing ---------------------------------------------------------------------------------
+static int timer_name_id(ks_ctx *ctx, const char *name) {
+    for (size_t i = 0; i < ctx->t_names.size(); i++)
+        if (ctx->t_names[i] == name) return (int)i;
+    ctx->t_names.push_back(name);
+    ctx->t_launches.push_back(0);
+    ctx->t_ms.push_back(0.0);
+    return (int)ctx->t_names.size() - 1;
+}
+
+static void timer_resolve(ks_ctx *ctx) {
+    if (ctx->t_pending.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->t_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            ctx->t_ms[t.name_id] += ms;
+            ctx->t_launches[t.name_id] += 1;
+        }
+        ctx->t_free.push_back({t.a, t.b});
+    }
+    ctx->t_pending.clear();
+}
+
+void ks_timer_begin(ks_ctx *ctx, const char *name) {
+    if (!ctx->timing) return;
+    if (ctx->t_pending.size() >= 4096) timer_resolve(ctx);
+    ks_timer_slot s;
+    if (!ctx->t_free.empty()) {
+        s.a = ctx->t_free.back().first; s.b = ctx->t_free.back().second;
+        ctx->t_free.pop_back();
+    } else {
+        (void)hipEventCreate(&s.a);
+        (void)hipEventCreate(&s.b);
+    }
+    s.name_id = timer_name_id(ctx, name);
+    (void)hipEventRecord(s.a, ctx->stream);
+    ctx->t_pending.push_back(s);
+}
+
+void ks_timer_end(ks_ctx *ctx) {
+    if (!ctx->timing || ctx->t_pending.empty()) return;
+    (void)hipEventRecord(ctx->t_pending.back().b, ctx->stream);
+}
+
+extern "C" int ks_timing_enable(ks_ctx *ctx, int enable) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (!enable) timer_resolve(ctx);
+    ctx->timing = enable != 0;
+    return KS_OK;
+}
+
+extern "C" int ks_timing_reset(ks_ctx *ctx) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    timer_resolve(ctx);
+    for (auto &v : ctx->t_ms) v = 0.0;
+    for (auto &v : ctx->t_launches) v = 0;
+    return KS_OK;
+}
+
+extern "C" int ks_timing_get(ks_ctx *ctx, ks_kernel_time *rows, uint32_t cap, uint32_t *n) {
+    if (!ctx || !n) return KS_ERR_INVALID_ARG;
+    timer_resolve(ctx);
+    *n = (uint32_t)ctx->t_names.size();
+    for (uint32_t i = 0; i < *n && i < cap && rows; i++) {
+        memset(rows[i].name, 0, sizeof rows[i].name);
+        strncpy(rows[i].name, ctx->t_names[i].c_str(), sizeof rows[i].name - 1);
+        rows[i].launches = ctx->t_launches[i];
+        rows[i].total_ms = ctx->t_ms[i];
+    }
+    return KS_OK;
+}
+
+// ---- host-side pre-step: AminoAcidAmbiguity::validate_and_resolve, src/rust/aminoacid.rs:74-105 ----
+static inline u64 splitmix64(u64 *s) {
+    u64 z = (*s += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+extern "C" int ks_validate_and_resolve(const uint8_t *seq, uint64_t len, int upper, uint64_t rng_seed,
+                                       uint8_t *out, uint64_t *out_len, ks_residue_error *err) {
+    if ((!seq && len) || !out || !out_len) return KS_ERR_INVALID_ARG;
+    // class LUT: 0 invalid, 1 plain valid (20 standard + X U O), 2 stop, 3/4/5 = B/Z/J
+    static u8 cls[256];
+    static bool init = false;
+    if (!init) {
+        memset(cls, 0, sizeof cls);
+        for (const char *p = "ACDEFGHIKLMNPQRSTVWYXUO"; *p; p++) cls[(u8)*p] = 1; // aminoacid.rs:8-14
+        cls[(u8)'*'] = 2;
+        cls[(u8)'B'] = 3; cls[(u8)'Z'] = 4; cls[(u8)'J'] = 5; // aminoacid.rs:32-36
+        init = true;
+    }
+    u64 n = 0, rng = rng_seed, bits = 0;
+    int nbits = 0;
+    for (u64 i = 0; i < len; i++) {
+        u8 c = seq[i];
+        if (upper && c >= 'a' && c <= 'z') c = (u8)(c - 32); // index.rs:1000
+        u8 k = cls[c];
+        if (k == 2) { out[n++] = c; break; }                  // aminoacid.rs:79-83
+        if (k == 0) {                                         // aminoacid.rs:85-87
+            if (err) { err->seq_index = 0; err->position = (u32)(n + 1); err->residue = c; }
+            *out_len = n;
+            return KS_ERR_INVALID_RESIDUE;
+        }
+        if (k >= 3) {
+            if (nbits == 0) { bits = splitmix64(&rng); nbits = 64; }
+            int pick = (int)(bits & 1); bits >>= 1; nbits--;
+            static const char *cand[3] = {"DN", "EQ", "IL"};
+            c = (u8)cand[k - 3][pick];
+        }
+        out[n++] = c;
+    }
+    *out_len = n;
+    return KS_OK;
+}

@@ -1,0 +1,96 @@
+// ks_device.h — device-side building blocks: MurmurHash3_x64_128.h1, wave/block scans.
+// Written for gfx950: 64-lane waves, DPP/shuffle wave scans, LDS cross-wave combine.
+#pragma once
+#include "ks_common.h"
+
+#define KS_DEV __device__ __forceinline__
+
+KS_DEV u64 ks_rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+
+KS_DEV u64 ks_fmix64(u64 k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+
+#define KS_C1 0x87c37b91114253d5ULL
+#define KS_C2 0x4cf5ad432745937fULL
+
+// Streaming state of MurmurHash3_x64_128 (both lanes seeded), as sourmash::_hash_murmur uses it
+// (reference call site src/rust/index.rs:766; add_protein via src/rust/signature.rs:274).
+struct ks_murmur {
+    u64 h1, h2;
+    KS_DEV void init(u64 seed) { h1 = seed; h2 = seed; }
+    KS_DEV void block(u64 k1, u64 k2) {
+        k1 *= KS_C1; k1 = ks_rotl64(k1, 31); k1 *= KS_C2; h1 ^= k1;
+        h1 = ks_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
+        k2 *= KS_C2; k2 = ks_rotl64(k2, 33); k2 *= KS_C1; h2 ^= k2;
+        h2 = ks_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
+    }
+    // tail: k1 = bytes 0..7 (already masked), k2 = bytes 8..14 (already masked); t = len & 15
+    KS_DEV void tail(u64 k1, u64 k2, u32 t) {
+        if (t > 8) { k2 *= KS_C2; k2 = ks_rotl64(k2, 33); k2 *= KS_C1; h2 ^= k2; }
+        if (t > 0) { k1 *= KS_C1; k1 = ks_rotl64(k1, 31); k1 *= KS_C2; h1 ^= k1; }
+    }
+    KS_DEV u64 finish(u64 len) {
+        h1 ^= len; h2 ^= len;
+        h1 += h2; h2 += h1;
+        h1 = ks_fmix64(h1); h2 = ks_fmix64(h2);
+        return h1 + h2;
+    }
+};
+
+// bytes [8*I, 8*I+8) of the 16-byte little-endian pair (a, b): a funnel shift with a
+// compile-time byte count, which hipcc lowers to v_alignbit/v_perm.
+template <int I>
+KS_DEV u64 ks_funnel(u64 a, u64 b) {
+    if constexpr (I == 0) return a;
+    else return (a >> (8 * I)) | (b << (64 - 8 * I));
+}
+
+KS_DEV u64 ks_funnel_rt(u64 a, u64 b, u32 byte_shift) {
+    u32 s = byte_shift * 8;
+    return s ? ((a >> s) | (b << (64 - s))) : a;
+}
+
+KS_DEV u64 ks_mask_bytes(u32 n) { return n >= 8 ? ~0ULL : ((1ULL << (8 * n)) - 1ULL); }
+
+// ---- wave / block exclusive scans (u32) ----
+KS_DEV u32 ks_wave_incl_scan(u32 v) {
+    const u32 lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (lane >= (u32)d) v += t;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan; `smem` must hold (blockDim.x/64 + 1) u32.  Returns the exclusive
+// prefix of v; *total receives the block sum.  Contains three __syncthreads().
+KS_DEV u32 ks_block_excl_scan(u32 v, u32 *smem, u32 *total) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    u32 incl = ks_wave_incl_scan(v);
+    if (lane == 63) smem[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        u32 w = lane < nw ? smem[lane] : 0;
+        u32 wi = ks_wave_incl_scan(w);
+        if (lane < nw) smem[lane] = wi - w;
+        if (lane == nw - 1) smem[nw] = wi;
+    }
+    __syncthreads();
+    u32 base = smem[wave];
+    *total = smem[nw];
+    __syncthreads(); // smem may be reused by the caller right away
+    return base + incl - v;
+}
+
+KS_DEV u64 ks_ballot(bool p) { return __ballot(p); }
+KS_DEV u32 ks_lane_lt_count(u64 mask) {
+    // number of set bits of mask in lanes below this one
+    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0));
+}

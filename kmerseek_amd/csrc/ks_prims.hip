@@ -1,0 +1,284 @@
+// ks_prims.hip — device-wide primitives written for gfx950: exclusive scans and a stable LSD
+// radix sort (8-bit digits) for (u64 key, u32|u64 value) records.  Integer / HBM-bound work:
+// coalesced 8..16-B per-lane accesses, LDS-staged scatter so each digit leaves as a contiguous run.
+#include "ks_device.h"
+
+// =============================================================================================
+// scans
+// =============================================================================================
+template <typename T>
+KS_DEV T wave_incl_scan_t(T v) {
+    const u32 lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T t = __shfl_up(v, d, 64);
+        if (lane >= (u32)d) v += t;
+    }
+    return v;
+}
+
+template <typename T>
+KS_DEV T block_excl_scan_t(T v, T *smem /* blockDim/64 + 1 */, T *total) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    T incl = wave_incl_scan_t<T>(v);
+    if (lane == 63) smem[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        T w = lane < nw ? smem[lane] : (T)0;
+        T wi = wave_incl_scan_t<T>(w);
+        if (lane < nw) smem[lane] = wi - w;
+        if (lane == nw - 1) smem[nw] = wi;
+    }
+    __syncthreads();
+    T base = smem[wave];
+    *total = smem[nw];
+    __syncthreads();
+    return base + incl - v;
+}
+
+#define SCAN_THREADS 256
+#define SCAN_IPT 8
+#define SCAN_TILE (SCAN_THREADS * SCAN_IPT)
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const TIn *in, TOut *block_sums, u64 n) {
+    __shared__ TOut smem[SCAN_THREADS / 64 + 1];
+    const u64 base = (u64)blockIdx.x * SCAN_TILE;
+    TOut s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) {
+        u64 idx = base + (u64)i * SCAN_THREADS + threadIdx.x;
+        if (idx < n) s += (TOut)in[idx];
+    }
+    TOut total;
+    (void)block_excl_scan_t<TOut>(s, smem, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// out[i] = block_offsets[block] + exclusive prefix within the tile.  in may alias out.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const TIn *in, TOut *out, const TOut *block_offsets,
+                                                             u64 n, TOut *total_out) {
+    __shared__ TOut smem[SCAN_THREADS / 64 + 1];
+    const u64 base = (u64)blockIdx.x * SCAN_TILE + (u64)threadIdx.x * SCAN_IPT;
+    TOut v[SCAN_IPT];
+    TOut s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) {
+        u64 idx = base + i;
+        v[i] = idx < n ? (TOut)in[idx] : (TOut)0;
+        s += v[i];
+    }
+    TOut total;
+    TOut ex = block_excl_scan_t<TOut>(s, smem, &total);
+    TOut off = (block_offsets ? block_offsets[blockIdx.x] : (TOut)0) + ex;
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) {
+        u64 idx = base + i;
+        if (idx < n) out[idx] = off;
+        off += v[i];
+    }
+    // the thread that owns the last element also publishes the grand total
+    if (total_out && base <= n - 1 && n - 1 < base + SCAN_IPT) *total_out = off;
+}
+
+// single-block scan of a small array in place (n <= SCAN_TILE)
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_small(T *data, u64 n) {
+    __shared__ T smem[SCAN_THREADS / 64 + 1];
+    const u64 base = (u64)threadIdx.x * SCAN_IPT;
+    T v[SCAN_IPT];
+    T s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) {
+        v[i] = base + i < n ? data[base + i] : (T)0;
+        s += v[i];
+    }
+    T total;
+    T off = block_excl_scan_t<T>(s, smem, &total);
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) {
+        if (base + i < n) data[base + i] = off;
+        off += v[i];
+    }
+}
+
+template <typename TIn, typename TOut>
+static int scan_generic(ks_ctx *ctx, const TIn *in, TOut *out, u64 n, TOut *d_total) {
+    if (n == 0) {
+        if (d_total) KS_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(TOut), ctx->stream));
+        return KS_OK;
+    }
+    u64 nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nblocks == 1) {
+        KS_LAUNCH(ctx, "scan_apply", (k_scan_apply<TIn, TOut>), 1, SCAN_THREADS, in, out, (const TOut *)nullptr, n, d_total);
+        return KS_OK;
+    }
+    TOut *sums = nullptr;
+    KS_TRY(ks_alloc(ctx, &sums, nblocks));
+    KS_LAUNCH(ctx, "scan_reduce", (k_scan_reduce<TIn, TOut>), (u32)nblocks, SCAN_THREADS, in, sums, n);
+    int st;
+    if (nblocks <= SCAN_TILE) {
+        KS_LAUNCH(ctx, "scan_small", (k_scan_small<TOut>), 1, SCAN_THREADS, sums, nblocks);
+        st = KS_OK;
+    } else {
+        st = scan_generic<TOut, TOut>(ctx, sums, sums, nblocks, (TOut *)nullptr);
+    }
+    if (st == KS_OK) {
+        ks_timer_begin(ctx, "scan_apply");
+        hipLaunchKernelGGL((k_scan_apply<TIn, TOut>), dim3((u32)nblocks), dim3(SCAN_THREADS), 0, ctx->stream, in, out,
+                           (const TOut *)sums, n, d_total);
+        ks_timer_end(ctx);
+        if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "scan_apply launch failed");
+    }
+    ks_pool_free(ctx, sums); // stream-ordered reuse: later kernels on the same stream run after this one
+    return st;
+}
+
+int ks_scan_u32_to_u64(ks_ctx *ctx, const u32 *in, u64 *out, u64 n) {
+    // out[n] receives the total
+    return scan_generic<u32, u64>(ctx, in, out, n, out + n);
+}
+
+int ks_scan_u32_inplace(ks_ctx *ctx, u32 *data, u64 n, u32 *d_total) {
+    return scan_generic<u32, u32>(ctx, data, data, n, d_total);
+}
+
+// =============================================================================================
+// radix sort
+// =============================================================================================
+#define RS_THREADS 256
+#define RS_IPT 8
+#define RS_TILE (RS_THREADS * RS_IPT)
+#define RS_WAVES (RS_THREADS / 64)
+
+// hist[d * nblocks + block] = number of keys of this block's tile with digit d
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 *hist, u64 n, int shift, u32 nblocks) {
+    __shared__ u32 bins[256];
+    bins[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_IPT; i++) {
+        u64 idx = base + (u64)i * RS_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&bins[(u32)(keys[idx] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(u64)threadIdx.x * nblocks + blockIdx.x] = bins[threadIdx.x];
+}
+
+// Stable scatter.  Item order inside a tile is (wave, round, lane) = ascending global index, so
+// ranks computed per wave with ballot-matching + per-wave digit counters preserve input order.
+template <typename V>
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const u64 *kin, const V *vin, u64 *kout, V *vout,
+                                                              const u32 *goffs, u64 n, int shift, u32 nblocks) {
+    __shared__ u32 wcnt[RS_WAVES][256];
+    __shared__ u32 dstart[256];
+    __shared__ u32 scan_smem[RS_WAVES + 1];
+    __shared__ u64 skeys[RS_TILE];
+    __shared__ V svals[RS_TILE];
+
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int w = 0; w < RS_WAVES; w++) wcnt[w][tid] = 0;
+    __syncthreads();
+
+    const u64 tile_base = (u64)blockIdx.x * RS_TILE;
+    const u64 wbase = tile_base + (u64)wave * (64 * RS_IPT);
+    u64 key[RS_IPT];
+    V val[RS_IPT];
+    u32 rank[RS_IPT]; // (digit << 16) | rank within (wave, digit)
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++) {
+        u64 idx = wbase + (u64)r * 64 + lane;
+        bool valid = idx < n;
+        key[r] = valid ? kin[idx] : ~0ULL;
+        val[r] = valid ? vin[idx] : (V)0;
+        u32 d = valid ? ((u32)(key[r] >> shift) & 255u) : 255u;
+        // lanes holding the same digit
+        u64 peers = ~0ULL;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            u64 m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        u32 below = ks_lane_lt_count(peers);
+        u32 cnt = (u32)__popcll(peers);
+        u32 leader = (u32)__ffsll((long long)peers) - 1u;
+        u32 pre = 0;
+        if (lane == leader) { pre = wcnt[wave][d]; wcnt[wave][d] = pre + cnt; }
+        pre = __shfl(pre, (int)leader, 64);
+        rank[r] = (d << 16) | (pre + below);
+    }
+    __syncthreads();
+    // digit-major exclusive offsets: thread tid owns digit tid
+    {
+        u32 c[RS_WAVES];
+        u32 tot = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) { c[w] = wcnt[w][tid]; tot += c[w]; }
+        u32 total;
+        u32 ds = ks_block_excl_scan(tot, scan_smem, &total);
+        dstart[tid] = ds;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) { wcnt[w][tid] = ds; ds += c[w]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++) {
+        u32 d = rank[r] >> 16;
+        u32 pos = wcnt[wave][d] + (rank[r] & 0xffffu);
+        skeys[pos] = key[r];
+        svals[pos] = val[r];
+    }
+    __syncthreads();
+    const u64 remain = n - tile_base;
+    const u32 nvalid = remain < RS_TILE ? (u32)remain : RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_IPT; i++) {
+        u32 p = (u32)i * RS_THREADS + tid;
+        if (p < nvalid) {
+            u64 k = skeys[p];
+            u32 d = (u32)(k >> shift) & 255u;
+            u64 g = (u64)goffs[(u64)d * nblocks + blockIdx.x] + (p - dstart[d]);
+            kout[g] = k;
+            vout[g] = svals[p];
+        }
+    }
+}
+
+template <typename V>
+static int radix_sort_impl(ks_ctx *ctx, u64 **keys, V **vals, u64 *keys_alt, V *vals_alt, u64 n, int bit_lo, int bit_hi) {
+    if (n <= 1 || bit_hi <= bit_lo) return KS_OK;
+    if (n >= 0xffffffffULL) return ks_fail(ctx, KS_ERR_CAPACITY, "radix sort: %llu records exceed the 32-bit offset range", (unsigned long long)n);
+    const u32 nblocks = (u32)((n + RS_TILE - 1) / RS_TILE);
+    u32 *hist = nullptr;
+    KS_TRY(ks_alloc(ctx, &hist, (size_t)256 * nblocks));
+    u64 *kin = *keys, *kout = keys_alt;
+    V *vin = *vals, *vout = vals_alt;
+    int st = KS_OK;
+    for (int shift = bit_lo; shift < bit_hi && st == KS_OK; shift += 8) {
+        ks_timer_begin(ctx, "radix_hist");
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)kin, hist, n, shift, nblocks);
+        ks_timer_end(ctx);
+        st = ks_scan_u32_inplace(ctx, hist, (u64)256 * nblocks, nullptr);
+        if (st != KS_OK) break;
+        ks_timer_begin(ctx, sizeof(V) == 4 ? "radix_scatter_v32" : "radix_scatter_v64");
+        hipLaunchKernelGGL((k_radix_scatter<V>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)kin,
+                           (const V *)vin, kout, vout, (const u32 *)hist, n, shift, nblocks);
+        ks_timer_end(ctx);
+        if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "radix sort launch failed");
+        u64 *tk = kin; kin = kout; kout = tk;
+        V *tv = vin; vin = vout; vout = tv;
+    }
+    ks_pool_free(ctx, hist);
+    *keys = kin;
+    *vals = vin;
+    return st;
+}
+
+int ks_radix_sort_u32(ks_ctx *ctx, u64 **keys, u32 **vals, u64 *keys_alt, u32 *vals_alt, u64 n, int bit_lo, int bit_hi) {
+    return radix_sort_impl<u32>(ctx, keys, vals, keys_alt, vals_alt, n, bit_lo, bit_hi);
+}
+int ks_radix_sort_u64(ks_ctx *ctx, u64 **keys, u64 **vals, u64 *keys_alt, u64 *vals_alt, u64 n, int bit_lo, int bit_hi) {
+    return radix_sort_impl<u64>(ctx, keys, vals, keys_alt, vals_alt, n, bit_lo, bit_hi);
+}

@@ -1,0 +1,307 @@
+// ks_search.hip — inverted-index build and many-vs-many sketch search on gfx950.
+//
+// Replaces branchwater manysearch as called by do_manysearch(threshold=0, output_all=False)
+// (src/python/kmerseek/search.py:125-141): for every (query, target) pair with >= 1 shared hash,
+// intersect = |mins_q ∩ mins_t| and n_weighted = Σ target abundance over the shared hashes.
+// The reference does |Q|x|T| pairwise sorted merges; here both sides become postings sorted by hash
+// and are joined once (identical pair results, O(N log N) instead of O(|Q||T|(|q|+|t|))).
+//
+// Data layout in HBM (SoA, coalesced):
+//   index  : keys u64[N_T] ascending, tids u32[N_T], abunds u32[N_T]
+//   queries: postings (hash u64, qid u32) radix-sorted on the TOP 32 hash bits only — the join needs
+//            locality, not order: each query posting binary-searches its full 64-bit hash inside the
+//            narrow index range its chunk maps to (L2-resident).
+//   matches: (qid<<32|tid, abund) appended through a wave-aggregated atomic cursor, radix-sorted on the
+//            live id bits, then run-length reduced to COO sorted by (qid, tid).
+#include "ks_device.h"
+
+// one wave per sequence: value[j] = f(seq id) for every posting j of the sequence
+__global__ __launch_bounds__(256) void k_fill_index_vals(const u64 *csr, const u32 *abunds, u32 n_seqs, u64 *vals) {
+    const u32 s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_seqs) return;
+    const u64 b = csr[s], e = csr[s + 1];
+    for (u64 j = b + (threadIdx.x & 63); j < e; j += 64) vals[j] = ((u64)abunds[j] << 32) | s;
+}
+
+__global__ __launch_bounds__(256) void k_fill_query_vals(const u64 *csr, u32 n_seqs, u32 *vals) {
+    const u32 s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_seqs) return;
+    const u64 b = csr[s], e = csr[s + 1];
+    for (u64 j = b + (threadIdx.x & 63); j < e; j += 64) vals[j] = s;
+}
+
+__global__ __launch_bounds__(256) void k_split_vals(const u64 *vals, u64 n, u32 *tids, u32 *abunds) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 v = vals[i];
+    tids[i] = (u32)v;
+    abunds[i] = (u32)(v >> 32);
+}
+
+int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
+    if (!t || !out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    ks_index *ix = new ks_index();
+    memset(ix, 0, sizeof *ix);
+    ix->ctx = ctx;
+    ix->params = t->params;
+    ix->n_targets = t->n_seqs;
+    ix->n_postings = t->n_hashes;
+    const u64 n = t->n_hashes;
+    u64 *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr;
+    int st = KS_OK;
+#define IX_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
+#define IX_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
+    IX_CHECK(ks_alloc(ctx, &k0, (size_t)n));
+    IX_CHECK(ks_alloc(ctx, &k1, (size_t)n));
+    IX_CHECK(ks_alloc(ctx, &v0, (size_t)n));
+    IX_CHECK(ks_alloc(ctx, &v1, (size_t)n));
+    IX_CHECK(ks_alloc(ctx, &ix->d_tids, (size_t)n));
+    IX_CHECK(ks_alloc(ctx, &ix->d_abunds, (size_t)n));
+    if (n > 0) {
+        IX_HIP(hipMemcpyAsync(k0, t->d_hashes, (size_t)n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+        ks_timer_begin(ctx, "fill_index_vals");
+        hipLaunchKernelGGL(k_fill_index_vals, dim3((t->n_seqs + 3) / 4), dim3(256), 0, ctx->stream, (const u64 *)t->d_offsets,
+                           (const u32 *)t->d_abunds, t->n_seqs, v0);
+        ks_timer_end(ctx);
+        IX_HIP(hipGetLastError());
+        u64 *ks = k0, *vs = v0;
+        IX_CHECK(ks_radix_sort_u64(ctx, &ks, &vs, k1, v1, n, 0, 64));
+        ks_timer_begin(ctx, "split_vals");
+        hipLaunchKernelGGL(k_split_vals, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u64 *)vs, n, ix->d_tids, ix->d_abunds);
+        ks_timer_end(ctx);
+        IX_HIP(hipGetLastError());
+        // keep the sorted key buffer, release the other
+        if (ks == k0) { ix->d_keys = k0; k0 = nullptr; } else { ix->d_keys = k1; k1 = nullptr; }
+    } else {
+        ix->d_keys = k0; k0 = nullptr;
+    }
+    IX_HIP(hipStreamSynchronize(ctx->stream));
+done:
+    ks_pool_free(ctx, k0); ks_pool_free(ctx, k1); ks_pool_free(ctx, v0); ks_pool_free(ctx, v1);
+    if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_index_free(ix); return st; }
+    *out = ix;
+    return KS_OK;
+#undef IX_CHECK
+#undef IX_HIP
+}
+
+// ---------------------------------------------------------------------------------------------
+// join
+// ---------------------------------------------------------------------------------------------
+#define JN_THREADS 256
+#define JN_IPT 8
+#define JN_TILE (JN_THREADS * JN_IPT)
+
+KS_DEV u64 jn_lower_bound(const u64 *a, u64 lo, u64 hi, u64 x) {
+    while (lo < hi) {
+        u64 mid = lo + ((hi - lo) >> 1);
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// cursor[0] = matches appended so far (keeps counting past `cap` so the host can size a retry)
+__global__ __launch_bounds__(JN_THREADS) void k_join(const u64 *qkeys, const u32 *qids, u64 n_q, const u64 *ikeys,
+                                                     const u32 *itids, const u32 *iabunds, u64 n_t, u64 *pair_keys,
+                                                     u32 *pair_vals, u64 cap, unsigned long long *cursor) {
+    __shared__ u64 red[JN_THREADS / 64][2];
+    __shared__ u64 range[2];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = (u64)blockIdx.x * JN_TILE;
+    u64 key[JN_IPT];
+    u32 qid[JN_IPT];
+    u64 mn = ~0ULL, mx = 0;
+#pragma unroll
+    for (int i = 0; i < JN_IPT; i++) {
+        u64 idx = base + (u64)i * JN_THREADS + tid;
+        bool v = idx < n_q;
+        key[i] = v ? qkeys[idx] : 0;
+        qid[i] = v ? qids[idx] : 0xffffffffu;
+        if (v) { mn = key[i] < mn ? key[i] : mn; mx = key[i] > mx ? key[i] : mx; }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        u64 a = __shfl_down(mn, d, 64), b = __shfl_down(mx, d, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (lane == 0) { red[wave][0] = mn; red[wave][1] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < JN_THREADS / 64; w++) { mn = red[w][0] < mn ? red[w][0] : mn; mx = red[w][1] > mx ? red[w][1] : mx; }
+        u64 lo = jn_lower_bound(ikeys, 0, n_t, mn);
+        u64 hi = mx == ~0ULL ? n_t : jn_lower_bound(ikeys, lo, n_t, mx + 1);
+        range[0] = lo; range[1] = hi;
+    }
+    __syncthreads();
+    const u64 lo = range[0], hi = range[1];
+    if (lo >= hi) return;
+#pragma unroll
+    for (int i = 0; i < JN_IPT; i++) {
+        if (qid[i] == 0xffffffffu) continue;
+        u64 j = jn_lower_bound(ikeys, lo, hi, key[i]);
+        while (j < hi && ikeys[j] == key[i]) {
+            unsigned long long slot = atomicAdd(cursor, 1ULL);
+            if (slot < cap) {
+                pair_keys[slot] = ((u64)qid[i] << 32) | itids[j];
+                pair_vals[slot] = iabunds[j];
+            }
+            j++;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pair reduce: sorted (qid<<32|tid, abund) -> COO rows
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pair_heads(const u64 *keys, u64 n, u32 *heads) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    heads[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// hidx = exclusive scan of heads; row r starts where hidx steps from r to r+1
+__global__ __launch_bounds__(256) void k_pair_rows(const u64 *keys, const u32 *vals, const u32 *hidx, u64 n, u32 n_rows,
+                                                   u64 *row_start) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool head = (i == 0) || keys[i] != keys[i - 1];
+    if (head) row_start[hidx[i]] = i;
+    if (i == 0) row_start[n_rows] = n;
+}
+
+__global__ __launch_bounds__(256) void k_pair_emit(const u64 *keys, const u32 *vals, const u64 *row_start, u32 n_rows,
+                                                   u32 *qid, u32 *tid, u32 *isect, u64 *nw) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    u64 b = row_start[r], e = row_start[r + 1];
+    u64 k = keys[b];
+    u64 w = 0;
+    for (u64 j = b; j < e; j++) w += vals[j];
+    qid[r] = (u32)(k >> 32);
+    tid[r] = (u32)k;
+    isect[r] = (u32)(e - b);
+    nw[r] = w;
+}
+
+static int bits_for(u32 n) { // bits needed to represent ids 0..n-1
+    int b = 0;
+    while (b < 32 && (n > (1u << b))) b++;
+    return b < 1 ? 1 : b;
+}
+
+int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out) {
+    if (!ix || !q || !out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    if (ix->params.ksize != q->params.ksize || ix->params.scaled != q->params.scaled ||
+        ix->params.moltype != q->params.moltype || ix->params.seed != q->params.seed)
+        return ks_fail(ctx, KS_ERR_INVALID_ARG, "query sketches and index were built with different parameters");
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    ks_hits *H = new ks_hits();
+    memset(H, 0, sizeof *H);
+    H->ctx = ctx;
+    const u64 n_q = q->n_hashes, n_t = ix->n_postings;
+    u64 *qk0 = nullptr, *qk1 = nullptr, *pk0 = nullptr, *pk1 = nullptr, *row_start = nullptr;
+    u32 *qv0 = nullptr, *qv1 = nullptr, *pv0 = nullptr, *pv1 = nullptr, *heads = nullptr, *d_nrows = nullptr;
+    unsigned long long *cursor = nullptr;
+    int st = KS_OK;
+#define SE_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
+#define SE_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
+    if (n_q == 0 || n_t == 0) {
+        SE_CHECK(ks_alloc(ctx, &H->d_qid, 1)); SE_CHECK(ks_alloc(ctx, &H->d_tid, 1));
+        SE_CHECK(ks_alloc(ctx, &H->d_isect, 1)); SE_CHECK(ks_alloc(ctx, &H->d_nw, 1));
+        *out = H;
+        return KS_OK;
+    }
+    {
+        // query postings, sorted on the top 32 hash bits
+        SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qk1, (size_t)n_q));
+        SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qv1, (size_t)n_q));
+        SE_HIP(hipMemcpyAsync(qk0, q->d_hashes, (size_t)n_q * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+        ks_timer_begin(ctx, "fill_query_vals");
+        hipLaunchKernelGGL(k_fill_query_vals, dim3((q->n_seqs + 3) / 4), dim3(256), 0, ctx->stream, (const u64 *)q->d_offsets, q->n_seqs, qv0);
+        ks_timer_end(ctx);
+        SE_HIP(hipGetLastError());
+        u64 *qk = qk0;
+        u32 *qv = qv0;
+        SE_CHECK(ks_radix_sort_u32(ctx, &qk, &qv, qk1, qv1, n_q, 32, 64));
+
+        // join, with a retry if the match list outgrows its first guess
+        SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, 1));
+        u64 cap = n_q < (1u << 20) ? (1u << 20) : n_q;
+        u64 n_pairs = 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            SE_CHECK(ks_alloc(ctx, &pk0, (size_t)cap)); SE_CHECK(ks_alloc(ctx, &pv0, (size_t)cap));
+            SE_HIP(hipMemsetAsync(cursor, 0, sizeof(u64), ctx->stream));
+            ks_timer_begin(ctx, "join");
+            hipLaunchKernelGGL(k_join, dim3((u32)((n_q + JN_TILE - 1) / JN_TILE)), dim3(JN_THREADS), 0, ctx->stream,
+                               (const u64 *)qk, (const u32 *)qv, n_q, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids,
+                               (const u32 *)ix->d_abunds, n_t, pk0, pv0, cap, cursor);
+            ks_timer_end(ctx);
+            SE_HIP(hipGetLastError());
+            SE_HIP(hipMemcpyAsync(ctx->h_pin, cursor, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+            SE_HIP(hipStreamSynchronize(ctx->stream));
+            n_pairs = ctx->h_pin[0];
+            if (n_pairs <= cap) break;
+            if (attempt == 1 || n_pairs >= 0xfffffff0ULL) {
+                st = ks_fail(ctx, KS_ERR_CAPACITY, "search produced %llu matched posting pairs (cap %llu)",
+                             (unsigned long long)n_pairs, (unsigned long long)cap);
+                goto done;
+            }
+            ks_pool_free(ctx, pk0); ks_pool_free(ctx, pv0); pk0 = nullptr; pv0 = nullptr;
+            cap = n_pairs;
+        }
+        ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
+        qk0 = qk1 = nullptr; qv0 = qv1 = nullptr;
+        H->n_pair_instances = n_pairs;
+        if (n_pairs == 0) {
+            SE_CHECK(ks_alloc(ctx, &H->d_qid, 1)); SE_CHECK(ks_alloc(ctx, &H->d_tid, 1));
+            SE_CHECK(ks_alloc(ctx, &H->d_isect, 1)); SE_CHECK(ks_alloc(ctx, &H->d_nw, 1));
+            goto done;
+        }
+        // sort matches by (qid, tid) on the live id bits only
+        SE_CHECK(ks_alloc(ctx, &pk1, (size_t)n_pairs)); SE_CHECK(ks_alloc(ctx, &pv1, (size_t)n_pairs));
+        u64 *pk = pk0;
+        u32 *pv = pv0;
+        const int tb = (bits_for(ix->n_targets) + 7) / 8 * 8, qb = (bits_for(q->n_seqs) + 7) / 8 * 8;
+        SE_CHECK(ks_radix_sort_u32(ctx, &pk, &pv, pk1, pv1, n_pairs, 0, tb));
+        {
+            u64 *alt_k = (pk == pk0) ? pk1 : pk0;
+            u32 *alt_v = (pv == pv0) ? pv1 : pv0;
+            SE_CHECK(ks_radix_sort_u32(ctx, &pk, &pv, alt_k, alt_v, n_pairs, 32, 32 + qb));
+        }
+        // run-length reduce
+        SE_CHECK(ks_alloc(ctx, &heads, (size_t)n_pairs));
+        SE_CHECK(ks_alloc(ctx, &d_nrows, 1));
+        const u32 gp = (u32)((n_pairs + 255) / 256);
+        ks_timer_begin(ctx, "pair_heads");
+        hipLaunchKernelGGL(k_pair_heads, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, n_pairs, heads);
+        ks_timer_end(ctx);
+        SE_CHECK(ks_scan_u32_inplace(ctx, heads, n_pairs, d_nrows));
+        SE_HIP(hipMemcpyAsync(ctx->h_pin, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        SE_HIP(hipStreamSynchronize(ctx->stream));
+        const u32 n_rows = *(u32 *)ctx->h_pin;
+        H->n_hits = n_rows;
+        SE_CHECK(ks_alloc(ctx, &row_start, (size_t)n_rows + 1));
+        SE_CHECK(ks_alloc(ctx, &H->d_qid, (size_t)n_rows)); SE_CHECK(ks_alloc(ctx, &H->d_tid, (size_t)n_rows));
+        SE_CHECK(ks_alloc(ctx, &H->d_isect, (size_t)n_rows)); SE_CHECK(ks_alloc(ctx, &H->d_nw, (size_t)n_rows));
+        ks_timer_begin(ctx, "pair_rows");
+        hipLaunchKernelGGL(k_pair_rows, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv, (const u32 *)heads,
+                           n_pairs, n_rows, row_start);
+        ks_timer_end(ctx);
+        ks_timer_begin(ctx, "pair_emit");
+        hipLaunchKernelGGL(k_pair_emit, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv,
+                           (const u64 *)row_start, n_rows, H->d_qid, H->d_tid, H->d_isect, H->d_nw);
+        ks_timer_end(ctx);
+        SE_HIP(hipGetLastError());
+        SE_HIP(hipStreamSynchronize(ctx->stream));
+    }
+done:
+    ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
+    ks_pool_free(ctx, pk0); ks_pool_free(ctx, pk1); ks_pool_free(ctx, pv0); ks_pool_free(ctx, pv1);
+    ks_pool_free(ctx, heads); ks_pool_free(ctx, d_nrows); ks_pool_free(ctx, row_start); ks_pool_free(ctx, cursor);
+    if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_hits_free(H); return st; }
+    *out = H;
+    return KS_OK;
+#undef SE_CHECK
+#undef SE_HIP
+}

@@ -1,0 +1,266 @@
+"""Object wrappers over the C ABI (include/kmerseek_amd.h): Context, Sketches, Index, Hits.
+
+Host arrays are numpy; device-resident inputs are passed as raw pointers (e.g. ``tensor.data_ptr()``),
+so nothing here depends on torch.  All compute happens in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import ks_params
+
+MOLTYPES = {"protein": _lib.KS_PROTEIN, "raw": _lib.KS_PROTEIN, "dayhoff": _lib.KS_DAYHOFF, "hp": _lib.KS_HP}
+MOLTYPE_NAMES = {_lib.KS_PROTEIN: "protein", _lib.KS_DAYHOFF: "dayhoff", _lib.KS_HP: "hp"}
+SEED = _lib.KS_SEED_DEFAULT  # src/rust/signature.rs:12
+
+
+class KmerseekError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+class InvalidAminoAcid(KmerseekError):
+    """IndexError::InvalidAminoAcid(char, position) — src/rust/errors.rs:14-15."""
+
+    def __init__(self, char: str, position: int, seq_index: int = 0):
+        super().__init__(_lib.KS_ERR_INVALID_RESIDUE, f"Invalid amino acid '{char}' found at position {position}")
+        self.char, self.position, self.seq_index = char, position, seq_index
+
+
+def moltype_id(moltype: str) -> int:
+    L = _lib.load()
+    out = C.c_uint32(0)
+    st = L.ks_moltype_from_string(moltype.encode(), C.byref(out))
+    if st != _lib.KS_OK:
+        # message of src/rust/encoding.rs:22-25
+        raise KmerseekError(st, f"Invalid moltype: {moltype}, only 'protein', 'hp', or 'dayhoff' are supported")
+    return out.value
+
+
+def make_params(ksize: int, scaled: int, moltype: str, seed: int = SEED) -> ks_params:
+    return ks_params(ksize=int(ksize), scaled=int(scaled), moltype=moltype_id(moltype), flags=0, seed=int(seed))
+
+
+def max_hash(scaled: int) -> int:
+    return int(_lib.load().ks_max_hash(int(scaled)))
+
+
+def validate_and_resolve(seq: bytes, upper: bool = False, rng_seed: int = 0) -> bytes:
+    """Host pre-step (src/rust/aminoacid.rs:74-105); raises InvalidAminoAcid."""
+    L = _lib.load()
+    out = C.create_string_buffer(len(seq) + 1)
+    out_len = C.c_uint64(0)
+    err = _lib.ks_residue_error()
+    st = L.ks_validate_and_resolve(seq, len(seq), 1 if upper else 0, rng_seed, out, C.byref(out_len), C.byref(err))
+    if st == _lib.KS_ERR_INVALID_RESIDUE:
+        raise InvalidAminoAcid(chr(err.residue), err.position)
+    if st != _lib.KS_OK:
+        raise KmerseekError(st, L.ks_status_string(st).decode())
+    return out.raw[:out_len.value]
+
+
+def pack(seqs: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+    """Concatenate records into (residues u8, offsets u64[n+1]) — the batch layout of the C ABI."""
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if len(seqs):
+        offs[1:] = np.cumsum([len(s) for s in seqs], dtype=np.uint64)
+    res = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy() if len(seqs) else np.zeros(0, np.uint8)
+    return res, offs
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One HIP device + stream + workspace (ks_ctx).  Not thread-safe: one per host thread."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        st = self._L.ks_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if st != _lib.KS_OK:
+            raise KmerseekError(st, f"ks_ctx_create(device={device}) failed: {self._L.ks_status_string(st).decode()}"
+                                    " — the HIP path has no CPU fallback")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ks_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, st: int):
+        if st != _lib.KS_OK:
+            msg = self._L.ks_last_error(self._h).decode() or self._L.ks_status_string(st).decode()
+            raise KmerseekError(st, msg)
+
+    @property
+    def stream(self) -> int:
+        return int(self._L.ks_ctx_stream(self._h) or 0)
+
+    def synchronize(self):
+        self._check(self._L.ks_ctx_synchronize(self._h))
+
+    # ---- sketch ----
+    def sketch_batch(self, residues: np.ndarray, offsets: np.ndarray, ksize: int, scaled: int, moltype: str,
+                     seed: int = SEED) -> "Sketches":
+        residues = np.ascontiguousarray(residues, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        p = make_params(ksize, scaled, moltype, seed)
+        out = C.c_void_p()
+        self._check(self._L.ks_sketch_batch(self._h, _ptr(residues), _ptr(offsets), len(offsets) - 1, C.byref(p),
+                                            C.byref(out)))
+        return Sketches(self, out)
+
+    def sketch_batch_device(self, d_residues: int, d_offsets: int, n_seqs: int, n_residues: int, ksize: int,
+                            scaled: int, moltype: str, max_seq_len: int = 0, seed: int = SEED) -> "Sketches":
+        p = make_params(ksize, scaled, moltype, seed)
+        out = C.c_void_p()
+        self._check(self._L.ks_sketch_batch_device(self._h, C.c_void_p(d_residues), C.c_void_p(d_offsets), n_seqs,
+                                                   n_residues, max_seq_len, C.byref(p), C.byref(out)))
+        return Sketches(self, out)
+
+    def sketches_from_host(self, offsets: np.ndarray, hashes: np.ndarray, abunds: np.ndarray, ksize: int,
+                           scaled: int, moltype: str, seed: int = SEED) -> "Sketches":
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        abunds = np.ascontiguousarray(abunds, dtype=np.uint32)
+        p = make_params(ksize, scaled, moltype, seed)
+        out = C.c_void_p()
+        self._check(self._L.ks_sketches_from_host(self._h, _ptr(offsets), _ptr(hashes), _ptr(abunds),
+                                                  len(offsets) - 1, C.byref(p), C.byref(out)))
+        return Sketches(self, out)
+
+    def kmer_positions(self, residues: np.ndarray, offsets: np.ndarray, ksize: int, scaled: int, moltype: str,
+                       seed: int = SEED) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(seq u32, start u32, hash u64) of every kept window, ordered by (seq, start)."""
+        residues = np.ascontiguousarray(residues, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        p = make_params(ksize, scaled, moltype, seed)
+        out = C.c_void_p()
+        self._check(self._L.ks_kmer_positions(self._h, _ptr(residues), _ptr(offsets), len(offsets) - 1, C.byref(p),
+                                              C.byref(out)))
+        try:
+            n = int(self._L.ks_kmerpos_count(out))
+            seq = np.zeros(n, np.uint32); start = np.zeros(n, np.uint32); h = np.zeros(n, np.uint64)
+            self._check(self._L.ks_kmerpos_copy_to_host(self._h, out, _ptr(seq), _ptr(start), _ptr(h)))
+        finally:
+            self._L.ks_kmerpos_free(out)
+        return seq, start, h
+
+    # ---- index / search ----
+    def index_build(self, targets: "Sketches") -> "Index":
+        out = C.c_void_p()
+        self._check(self._L.ks_index_build(self._h, targets._h, C.byref(out)))
+        return Index(self, out)
+
+    def search(self, index: "Index", queries: "Sketches") -> "Hits":
+        out = C.c_void_p()
+        self._check(self._L.ks_search(self._h, index._h, queries._h, C.byref(out)))
+        return Hits(self, out)
+
+    # ---- measurement ----
+    def timing_enable(self, on: bool = True):
+        self._check(self._L.ks_timing_enable(self._h, 1 if on else 0))
+
+    def timing_reset(self):
+        self._check(self._L.ks_timing_reset(self._h))
+
+    def timing(self) -> Dict[str, Tuple[int, float]]:
+        """{kernel name: (launches, total ms)} from HIP events on the context's stream."""
+        n = C.c_uint32(0)
+        rows = (_lib.ks_kernel_time * 64)()
+        self._check(self._L.ks_timing_get(self._h, rows, 64, C.byref(n)))
+        return {rows[i].name.decode(): (int(rows[i].launches), float(rows[i].total_ms)) for i in range(min(n.value, 64))}
+
+
+class _Owned:
+    _free = None
+
+    def __init__(self, ctx: Context, handle):
+        self._ctx, self._h = ctx, handle
+
+    def free(self):
+        if getattr(self, "_h", None) and self._ctx._h:
+            getattr(self._ctx._L, self._free)(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Sketches(_Owned):
+    """Device-resident CSR of per-sequence sketches (ks_sketches)."""
+    _free = "ks_sketches_free"
+
+    @property
+    def n_seqs(self) -> int:
+        return int(self._ctx._L.ks_sketches_n_seqs(self._h))
+
+    @property
+    def n_hashes(self) -> int:
+        return int(self._ctx._L.ks_sketches_n_hashes(self._h))
+
+    @property
+    def n_windows(self) -> int:
+        return int(self._ctx._L.ks_sketches_n_windows(self._h))
+
+    def to_host(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        n, m = self.n_seqs, self.n_hashes
+        offs = np.zeros(n + 1, np.uint64); hashes = np.zeros(m, np.uint64); abunds = np.zeros(m, np.uint32)
+        self._ctx._check(self._ctx._L.ks_sketches_copy_to_host(self._ctx._h, self._h, _ptr(offs), _ptr(hashes),
+                                                               _ptr(abunds)))
+        return offs, hashes, abunds
+
+
+class Index(_Owned):
+    _free = "ks_index_free"
+
+    @property
+    def n_targets(self) -> int:
+        return int(self._ctx._L.ks_index_n_targets(self._h))
+
+    @property
+    def n_postings(self) -> int:
+        return int(self._ctx._L.ks_index_n_postings(self._h))
+
+
+class Hits(_Owned):
+    _free = "ks_hits_free"
+
+    @property
+    def count(self) -> int:
+        return int(self._ctx._L.ks_hits_count(self._h))
+
+    @property
+    def n_pair_instances(self) -> int:
+        return int(self._ctx._L.ks_hits_n_pair_instances(self._h))
+
+    def to_host(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+        n = self.count
+        qid = np.zeros(n, np.uint32); tid = np.zeros(n, np.uint32)
+        isect = np.zeros(n, np.uint32); nw = np.zeros(n, np.uint64)
+        self._ctx._check(self._ctx._L.ks_hits_copy_to_host(self._ctx._h, self._h, _ptr(qid), _ptr(tid), _ptr(isect),
+                                                           _ptr(nw)))
+        return qid, tid, isect, nw

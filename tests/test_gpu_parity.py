@@ -1,0 +1,258 @@
+"""GPU parity: the HIP path, called through the C ABI, against the oracle and the committed goldens.
+Bit-exact everywhere (integer / index work).  Run on the GPU box with `pytest -m gpu`."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import kmerseek_amd as ks
+from kmerseek_amd import synth
+from oracle import oracle
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ks.Context(0)
+    yield c
+    c.close()
+
+
+def assert_sketch_parity(ctx, res, offs, k, scaled, mol):
+    S = ctx.sketch_batch(res, offs, k, scaled, mol)
+    got = S.to_host()
+    want = oracle.sketch_batch(res, offs, k, scaled, mol, n_threads=8)
+    assert S.n_seqs == len(offs) - 1
+    lens = (offs[1:] - offs[:-1]).astype(np.int64)
+    assert S.n_windows == int(np.maximum(lens - k + 1, 0).sum())
+    assert np.array_equal(got[0], want[0]), "CSR offsets differ"
+    assert np.array_equal(got[1], want[1]), "hashes differ"
+    assert np.array_equal(got[2], want[2]), "abundances differ"
+    return S, want
+
+
+# ---------------------------------------------------------------- goldens through the C ABI
+@pytest.mark.parametrize("key,ksize", [("hp.k15.scaled5", 15), ("hp.k16.scaled5", 16), ("hp.k24.scaled5", 24)])
+def test_golden_sketches(ctx, golden_sketches, bcl2_records, key, ksize):
+    sigs = {s["name"]: s for s in golden_sketches[key]["signatures"]}
+    res, offs = ks.pack([s for _, s in bcl2_records])
+    o, mins, abunds = ctx.sketch_batch(res, offs, ksize, 5, "hp").to_host()
+    for i, (name, _) in enumerate(bcl2_records):
+        g = sigs[name]
+        assert mins[int(o[i]):int(o[i + 1])].tolist() == g["mins"]
+        assert abunds[int(o[i]):int(o[i + 1])].tolist() == g["abundances"]
+
+
+def test_hash_kats(ctx, hash_kats):
+    seq = hash_kats["sequence"].encode()
+    for mol in ("protein", "dayhoff", "hp"):
+        res, offs = ks.pack([seq])
+        o, mins, abunds = ctx.sketch_batch(res, offs, 5, 1, mol).to_host()
+        rows = hash_kats[mol]
+        assert mins.tolist() == sorted(r["hash"] for r in rows)
+        by_hash = {r["hash"]: sum(len(p) for p in r["originals"].values()) for r in rows}
+        assert abunds.tolist() == [by_hash[h] for h in mins.tolist()]
+        seq_i, start, h = ctx.kmer_positions(res, offs, 5, 1, mol)
+        pos = {}
+        for s, hh in zip(start.tolist(), h.tolist()):
+            pos.setdefault(hh, []).append(s)
+        for r in rows:
+            assert sorted(pos[r["hash"]]) == sorted(p for ps in r["originals"].values() for p in ps)
+
+
+def test_index_kats(ctx, index_kats, bcl2_records):
+    for case in index_kats["bcl2_first25"]["cases"]:
+        seqs = [ks.validate_and_resolve(s, upper=True) for _, s in bcl2_records]
+        res, offs = ks.pack(seqs)
+        o, mins, _ = ctx.sketch_batch(res, offs, case["ksize"], case["scaled"], case["moltype"]).to_host()
+        keys = {}
+        for i in range(len(seqs)):
+            m = mins[int(o[i]):int(o[i + 1])]
+            keys[format(int(m.sum(dtype=np.uint64)), "x")] = len(m)
+        for kk, n in case["keys"].items():
+            assert keys[kk] == n
+        assert len(np.unique(mins)) == case["combined"]
+
+
+def test_golden_search(ctx, search_expected, ced9_records, bcl2_records):
+    k, sc, mol = search_expected["ksize"], search_expected["scaled"], search_expected["moltype"]
+    Q = ctx.sketch_batch(*ks.pack([s for _, s in ced9_records]), k, sc, mol)
+    T = ctx.sketch_batch(*ks.pack([s for _, s in bcl2_records]), k, sc, mol)
+    hits = ctx.search(ctx.index_build(T), Q)
+    qid, tid, isect, nw = hits.to_host()
+    names = [n for n, _ in bcl2_records]
+    got = {names[t]: (int(i), int(w)) for t, i, w in zip(tid.tolist(), isect.tolist(), nw.tolist())}
+    want = {r["match_name"]: (int(r["intersect_hashes"]), int(r["n_weighted_found"]))
+            for r in search_expected["manysearch_rows"]}
+    assert got == want and hits.count == 5 and set(qid.tolist()) == {0}
+
+
+# ---------------------------------------------------------------- oracle parity on seeded inputs
+@pytest.mark.parametrize("k,scaled,mol", [
+    (7, 1, "protein"), (10, 1, "protein"), (16, 5, "dayhoff"), (24, 5, "hp"), (5, 1, "hp"), (5, 1, "dayhoff"),
+    (8, 100, "dayhoff"), (3, 1, "protein"), (1, 1, "protein"), (15, 5, "hp"), (17, 1, "protein"),
+    (31, 2, "protein"), (32, 1, "dayhoff"), (33, 3, "hp"), (48, 1, "protein"), (100, 1, "hp"), (128, 7, "protein"),
+])
+def test_sketch_vs_oracle_synthetic(ctx, k, scaled, mol):
+    res, offs = synth.proteome(3000, stream=7 + k)
+    assert_sketch_parity(ctx, res, offs, k, scaled, mol)
+
+
+def test_sketch_ragged_and_edge_inputs(ctx):
+    rng = np.random.default_rng(5)
+    aa = list(b"ACDEFGHIKLMNPQRSTVWY")
+    seqs = [b"", b"A", b"ACDE", b"ACDEF", b"", b"", b"plantandanimalgenqmes", b"PLANTANDANIMALGENQMES",
+            b"XXXXXXXXXX", b"ACDEFXUO*BZJ", b"A" * 300, b"AC" * 700, b"W" * 5000, b"LIVINGALIVE"]
+    # long sequences: just over the tile limit, mid, very long, with repeats
+    for n in (1536, 1537, 1600, 4095, 4096, 4097, 9000, 40000):
+        seqs.append(bytes(rng.choice(aa, size=n).tolist()))
+    rep = bytes(rng.choice(aa, size=500).tolist())
+    seqs.append(rep * 20)  # 10k residues, every window 20x
+    seqs += [bytes(rng.choice(aa, size=int(n)).tolist()) for n in rng.integers(0, 400, 300)]
+    seqs += [b"", b""]
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    res, offs = ks.pack(seqs)
+    for k, scaled, mol in ((5, 1, "protein"), (7, 1, "hp"), (10, 2, "dayhoff"), (24, 5, "hp"), (21, 1, "protein")):
+        assert_sketch_parity(ctx, res, offs, k, scaled, mol)
+
+
+def test_sketch_empty_batches(ctx):
+    S = ctx.sketch_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64), 5, 1, "protein")
+    assert S.n_seqs == 0 and S.n_hashes == 0
+    S = ctx.sketch_batch(np.zeros(0, np.uint8), np.zeros(4, np.uint64), 5, 1, "protein")
+    o, h, a = S.to_host()
+    assert S.n_seqs == 3 and o.tolist() == [0, 0, 0, 0] and len(h) == 0
+
+
+def test_sketch_only_long_sequences(ctx):
+    rng = np.random.default_rng(11)
+    aa = list(b"ACDEFGHIKLMNPQRSTVWY")
+    seqs = [bytes(rng.choice(aa, size=n).tolist()) for n in (3000, 20000, 2000, 7777)]
+    res, offs = ks.pack(seqs)
+    assert_sketch_parity(ctx, res, offs, 10, 1, "protein")
+    assert_sketch_parity(ctx, res, offs, 16, 5, "dayhoff")
+
+
+def test_errors(ctx):
+    res, offs = ks.pack([b"ACDEFGHIK"])
+    with pytest.raises(ks.KmerseekError) as e:
+        ctx.sketch_batch(res, offs, 5, 1, "dna")
+    assert "Invalid moltype: dna" in str(e.value)
+    with pytest.raises(ks.KmerseekError) as e:
+        ctx.sketch_batch(res, offs, 0, 1, "protein")
+    assert e.value.status == ks._lib.KS_ERR_INVALID_KSIZE
+    with pytest.raises(ks.KmerseekError):
+        ctx.sketch_batch(res, offs, 5, 0, "protein")
+    with pytest.raises(ks.KmerseekError):
+        ctx.sketch_batch(res, np.array([0, 5, 3], np.uint64), 5, 1, "protein")
+
+
+def test_kmer_positions_vs_oracle(ctx):
+    res, offs = synth.proteome(400, stream=33)
+    for k, scaled, mol in ((10, 1, "protein"), (16, 5, "hp"), (24, 5, "hp"), (8, 3, "dayhoff")):
+        seq_i, start, h = ctx.kmer_positions(res, offs, k, scaled, mol)
+        o, mins, _ = oracle.sketch_batch(res, offs, k, scaled, mol, n_threads=4)
+        ws, wst, wh = [], [], []
+        for i in range(len(offs) - 1):
+            seq = bytes(res[int(offs[i]):int(offs[i + 1])])
+            st, hh = oracle.kmer_positions(seq, k, mol, mins[int(o[i]):int(o[i + 1])])
+            ws += [i] * len(st); wst += st.tolist(); wh += hh.tolist()
+        assert seq_i.tolist() == ws and start.tolist() == wst and h.tolist() == wh
+
+
+@pytest.mark.parametrize("k,scaled,mol,nt,nq", [
+    (7, 1, "protein", 2000, 1500), (16, 5, "dayhoff", 3000, 3000), (24, 5, "hp", 2500, 2500),
+    (5, 1, "hp", 120, 90),  # saturated alphabet: every pair shares hashes, thousands of matches per hash
+    (10, 1, "protein", 4000, 3000),
+])
+def test_search_vs_oracle(ctx, k, scaled, mol, nt, nq):
+    t_res, t_off = synth.proteome(nt, stream=50 + k)
+    q_res, q_off = synth.queries(nq, t_res, t_off, stream=51 + k)
+    T, want_t = assert_sketch_parity(ctx, t_res, t_off, k, scaled, mol)
+    Q, want_q = assert_sketch_parity(ctx, q_res, q_off, k, scaled, mol)
+    ix = ctx.index_build(T)
+    assert ix.n_targets == nt and ix.n_postings == T.n_hashes
+    hits = ctx.search(ix, Q)
+    got = hits.to_host()
+    want = oracle.manysearch(want_q[0], want_q[1], want_t[0], want_t[1], want_t[2], n_threads=8)
+    assert hits.count == len(want[0])
+    for g, w, name in zip(got, want, ("qid", "tid", "intersect", "n_weighted")):
+        assert np.array_equal(g, w), name
+    assert hits.n_pair_instances == int(want[2].sum())
+    # searching twice gives the same answer (workspace reuse)
+    again = ctx.search(ix, Q).to_host()
+    for g, w in zip(again, want):
+        assert np.array_equal(g, w)
+
+
+def test_search_self_and_empty(ctx):
+    t_res, t_off = synth.proteome(500, stream=77)
+    T = ctx.sketch_batch(t_res, t_off, 10, 1, "protein")
+    ix = ctx.index_build(T)
+    qid, tid, isect, nw = ctx.search(ix, T).to_host()
+    o, mins, ab = T.to_host()
+    sizes = (o[1:] - o[:-1]).astype(np.int64)
+    diag = {int(q): int(i) for q, t, i in zip(qid, tid, isect) if q == t}
+    assert all(diag[i] == sizes[i] for i in range(500) if sizes[i] > 0)
+    # sorted by (qid, tid)
+    key = qid.astype(np.uint64) << np.uint64(32) | tid.astype(np.uint64)
+    assert np.all(key[1:] > key[:-1])
+    # empty query set / mismatched params
+    E = ctx.sketch_batch(np.zeros(0, np.uint8), np.zeros(3, np.uint64), 10, 1, "protein")
+    assert ctx.search(ix, E).count == 0
+    other = ctx.sketch_batch(t_res, t_off, 9, 1, "protein")
+    with pytest.raises(ks.KmerseekError):
+        ctx.search(ix, other)
+
+
+def test_sketches_from_host_roundtrip(ctx, golden_sketches, ced9_records):
+    # sketches loaded from a .sig.zip can be indexed and searched without re-sketching
+    sigs = golden_sketches["hp.k16.scaled5"]["signatures"]
+    offs = np.zeros(len(sigs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(s["mins"]) for s in sigs])
+    mins = np.array([m for s in sigs for m in s["mins"]], np.uint64)
+    ab = np.array([a for s in sigs for a in s["abundances"]], np.uint32)
+    T = ctx.sketches_from_host(offs, mins, ab, 16, 5, "hp")
+    Q = ctx.sketch_batch(*ks.pack([s for _, s in ced9_records]), 16, 5, "hp")
+    hits = ctx.search(ctx.index_build(T), Q)
+    assert hits.count == 5
+    with pytest.raises(ks.KmerseekError):
+        ctx.sketches_from_host(np.array([0, 2], np.uint64), np.array([5, 5], np.uint64), np.array([1, 1], np.uint32),
+                               16, 5, "hp")
+
+
+def test_full_size_properties(ctx):
+    """Properties that do not need the oracle at full batch size: sortedness, uniqueness, abundance
+    sums = kept windows, idempotence, and agreement of two tilings of the same data."""
+    res, offs = synth.proteome(200000, stream=3)
+    k, scaled, mol = 10, 1, "protein"
+    S = ctx.sketch_batch(res, offs, k, scaled, mol)
+    o, h, a = S.to_host()
+    lens = (offs[1:] - offs[:-1]).astype(np.int64)
+    nwin = np.maximum(lens - k + 1, 0)
+    assert S.n_windows == int(nwin.sum())
+    # strictly ascending inside every sequence
+    d = h[1:] > h[:-1]
+    boundary = np.zeros(len(h), bool)
+    boundary[o[1:-1][o[1:-1] < len(h)].astype(np.int64)] = True
+    assert np.all(d | boundary[1:])
+    # scaled = 1: every window is kept, so abundances add up to the window count per sequence
+    csum = np.concatenate([[0], np.cumsum(a.astype(np.int64))])
+    per_seq = csum[o[1:].astype(np.int64)] - csum[o[:-1].astype(np.int64)]
+    assert np.array_equal(per_seq, nwin)
+    # idempotence
+    o2, h2, a2 = ctx.sketch_batch(res, offs, k, scaled, mol).to_host()
+    assert np.array_equal(o, o2) and np.array_equal(h, h2) and np.array_equal(a, a2)
+    # a sub-batch (different tile boundaries) reproduces the same per-sequence sketches
+    lo, hi = 1234, 91234
+    sub_offs = offs[lo:hi + 1] - offs[lo]
+    sub_res = res[int(offs[lo]):int(offs[hi])]
+    o3, h3, a3 = ctx.sketch_batch(sub_res, sub_offs, k, scaled, mol).to_host()
+    assert np.array_equal(h3, h[int(o[lo]):int(o[hi])]) and np.array_equal(a3, a[int(o[lo]):int(o[hi])])
+    # oracle spot check on a slice
+    w = oracle.sketch_batch(sub_res[:int(sub_offs[2000])], sub_offs[:2001], k, scaled, mol, n_threads=8)
+    assert np.array_equal(h3[:len(w[1])], w[1])
