@@ -8,9 +8,9 @@
 //
 // Data layout in HBM (SoA, coalesced):
 //   index  : keys u64[N_T] ascending, tids u32[N_T], abunds u32[N_T]
-//   queries: postings (hash u64, qid u32) radix-sorted on the TOP 32 hash bits only — the join needs
-//            locality, not order: each query posting binary-searches its full 64-bit hash inside the
-//            narrow index range its chunk maps to (L2-resident).
+//   queries: postings (hash u64, qid u32) radix-PARTITIONED on the top P <= 16 hash bits only — the join
+//            needs locality, not order: each query posting binary-searches its full 64-bit hash in the
+//            LDS-staged index keys of its bucket.
 //   matches: (qid<<32|tid, abund) appended through a wave-aggregated atomic cursor, radix-sorted on the
 //            live id bits, then run-length reduced to COO sorted by (qid, tid).
 #include "ks_device.h"
@@ -88,66 +88,92 @@ done:
 
 // ---------------------------------------------------------------------------------------------
 // join
+//
+// Murmur output is uniform, so the top P bits of the hash cut both posting lists into 2^P buckets of
+// near-equal size.  Query postings are only PARTITIONED on those bits (ceil(P/8) radix passes instead
+// of a 64-bit sort); the index is fully sorted once at build time.  One workgroup joins one bucket:
+// the bucket's index keys are staged in LDS (coalesced 8-B loads), every query posting of the bucket
+// binary-searches them there, and each match is appended to the pair list through an atomic cursor.
+// Buckets larger than the LDS stage (heavy duplicate hashes) are walked in chunks.
 // ---------------------------------------------------------------------------------------------
 #define JN_THREADS 256
-#define JN_IPT 8
-#define JN_TILE (JN_THREADS * JN_IPT)
+#define JN_CAP 6144 // index keys staged per chunk: 48 KiB of LDS -> 3 workgroups per CU
 
-KS_DEV u64 jn_lower_bound(const u64 *a, u64 lo, u64 hi, u64 x) {
+// dir[b] = first posting whose top `pbits` bits are >= b, for b in [0, 2^pbits]; keys are ordered on those bits
+__global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int pbits, u64 *dir) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 nb = 1u << pbits;
+    if (b > nb) return;
+    if (b == nb) { dir[b] = n; return; }
+    const int sh = 64 - pbits;
+    u64 lo = 0, hi = n;
     while (lo < hi) {
         u64 mid = lo + ((hi - lo) >> 1);
-        if (a[mid] < x) lo = mid + 1; else hi = mid;
+        u64 pre = pbits ? (keys[mid] >> sh) : 0;
+        if (pre < b) lo = mid + 1; else hi = mid;
+    }
+    dir[b] = lo;
+}
+
+KS_DEV u32 jn_lower_bound_lds(const u64 *lk, u32 n, u64 h) {
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        u32 mid = (lo + hi) >> 1;
+        if (lk[mid] < h) lo = mid + 1; else hi = mid;
     }
     return lo;
 }
 
-// cursor[0] = matches appended so far (keeps counting past `cap` so the host can size a retry)
-__global__ __launch_bounds__(JN_THREADS) void k_join(const u64 *qkeys, const u32 *qids, u64 n_q, const u64 *ikeys,
-                                                     const u32 *itids, const u32 *iabunds, u64 n_t, u64 *pair_keys,
-                                                     u32 *pair_vals, u64 cap, unsigned long long *cursor) {
-    __shared__ u64 red[JN_THREADS / 64][2];
-    __shared__ u64 range[2];
-    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 base = (u64)blockIdx.x * JN_TILE;
-    u64 key[JN_IPT];
-    u32 qid[JN_IPT];
-    u64 mn = ~0ULL, mx = 0;
-#pragma unroll
-    for (int i = 0; i < JN_IPT; i++) {
-        u64 idx = base + (u64)i * JN_THREADS + tid;
-        bool v = idx < n_q;
-        key[i] = v ? qkeys[idx] : 0;
-        qid[i] = v ? qids[idx] : 0xffffffffu;
-        if (v) { mn = key[i] < mn ? key[i] : mn; mx = key[i] > mx ? key[i] : mx; }
-    }
-    for (int d = 32; d > 0; d >>= 1) {
-        u64 a = __shfl_down(mn, d, 64), b = __shfl_down(mx, d, 64);
-        mn = a < mn ? a : mn;
-        mx = b > mx ? b : mx;
-    }
-    if (lane == 0) { red[wave][0] = mn; red[wave][1] = mx; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < JN_THREADS / 64; w++) { mn = red[w][0] < mn ? red[w][0] : mn; mx = red[w][1] > mx ? red[w][1] : mx; }
-        u64 lo = jn_lower_bound(ikeys, 0, n_t, mn);
-        u64 hi = mx == ~0ULL ? n_t : jn_lower_bound(ikeys, lo, n_t, mx + 1);
-        range[0] = lo; range[1] = hi;
-    }
-    __syncthreads();
-    const u64 lo = range[0], hi = range[1];
-    if (lo >= hi) return;
-#pragma unroll
-    for (int i = 0; i < JN_IPT; i++) {
-        if (qid[i] == 0xffffffffu) continue;
-        u64 j = jn_lower_bound(ikeys, lo, hi, key[i]);
-        while (j < hi && ikeys[j] == key[i]) {
-            unsigned long long slot = atomicAdd(cursor, 1ULL);
-            if (slot < cap) {
-                pair_keys[slot] = ((u64)qid[i] << 32) | itids[j];
-                pair_vals[slot] = iabunds[j];
-            }
-            j++;
+// cursor[0] = matches appended so far (keeps counting past `cap` so the host can size a retry).
+// Two passes per staged chunk: count matches per thread, reserve the workgroup's slice of the pair list
+// with ONE global atomic, then search again and write (an LDS search is far cheaper than a contended
+// device-wide atomic per match).
+__global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, const u32 *qids, const u64 *ikeys,
+                                                             const u32 *itids, const u32 *iabunds, const u64 *dir_q,
+                                                             const u64 *dir_t, u64 *pair_keys, u32 *pair_vals, u64 cap,
+                                                             unsigned long long *cursor) {
+    __shared__ u64 lk[JN_CAP];
+    __shared__ u32 scan_smem[JN_THREADS / 64 + 1];
+    __shared__ unsigned long long base_s;
+    const u32 tid = threadIdx.x;
+    const u64 qs = dir_q[blockIdx.x], qe = dir_q[blockIdx.x + 1];
+    const u64 ts = dir_t[blockIdx.x], te = dir_t[blockIdx.x + 1];
+    if (qs == qe || ts == te) return;
+    for (u64 c0 = ts; c0 < te; c0 += JN_CAP) {
+        const u32 n = (u32)((te - c0) < JN_CAP ? (te - c0) : JN_CAP);
+        for (u32 i = tid; i < n; i += JN_THREADS) lk[i] = ikeys[c0 + i];
+        __syncthreads();
+        u32 mine = 0;
+        for (u64 i = qs + tid; i < qe; i += JN_THREADS) {
+            const u64 h = qkeys[i];
+            u32 lo = jn_lower_bound_lds(lk, n, h);
+            while (lo < n && lk[lo] == h) { mine++; lo++; }
         }
+        u32 total;
+        const u32 off = ks_block_excl_scan(mine, scan_smem, &total);
+        if (total) { // uniform
+            if (tid == 0) base_s = atomicAdd(cursor, (unsigned long long)total);
+            __syncthreads();
+            u64 slot = base_s + off;
+            if (mine) {
+                for (u64 i = qs + tid; i < qe; i += JN_THREADS) {
+                    const u64 h = qkeys[i];
+                    u32 lo = jn_lower_bound_lds(lk, n, h);
+                    if (lo < n && lk[lo] == h) {
+                        const u32 q = qids[i];
+                        do {
+                            if (slot < cap) {
+                                pair_keys[slot] = ((u64)q << 32) | itids[c0 + lo];
+                                pair_vals[slot] = iabunds[c0 + lo];
+                            }
+                            slot++;
+                            lo++;
+                        } while (lo < n && lk[lo] == h);
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -200,7 +226,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
     memset(H, 0, sizeof *H);
     H->ctx = ctx;
     const u64 n_q = q->n_hashes, n_t = ix->n_postings;
-    u64 *qk0 = nullptr, *qk1 = nullptr, *pk0 = nullptr, *pk1 = nullptr, *row_start = nullptr;
+    u64 *qk0 = nullptr, *qk1 = nullptr, *pk0 = nullptr, *pk1 = nullptr, *row_start = nullptr, *dir_q = nullptr, *dir_t = nullptr;
     u32 *qv0 = nullptr, *qv1 = nullptr, *pv0 = nullptr, *pv1 = nullptr, *heads = nullptr, *d_nrows = nullptr;
     unsigned long long *cursor = nullptr;
     int st = KS_OK;
@@ -213,7 +239,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         return KS_OK;
     }
     {
-        // query postings, sorted on the top 32 hash bits
+        // query postings
         SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qk1, (size_t)n_q));
         SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qv1, (size_t)n_q));
         SE_HIP(hipMemcpyAsync(qk0, q->d_hashes, (size_t)n_q * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
@@ -223,7 +249,18 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         SE_HIP(hipGetLastError());
         u64 *qk = qk0;
         u32 *qv = qv0;
-        SE_CHECK(ks_radix_sort_u32(ctx, &qk, &qv, qk1, qv1, n_q, 32, 64));
+        // buckets of ~3k index postings; the query side is partitioned (not sorted) on the same top bits
+        int pbits = 0;
+        while (pbits < 16 && (n_t >> pbits) > 3072) pbits++;
+        SE_CHECK(ks_radix_sort_u32(ctx, &qk, &qv, qk1, qv1, n_q, 64 - pbits, 64));
+        const u32 n_buckets = 1u << pbits;
+        SE_CHECK(ks_alloc(ctx, &dir_q, (size_t)n_buckets + 1));
+        SE_CHECK(ks_alloc(ctx, &dir_t, (size_t)n_buckets + 1));
+        ks_timer_begin(ctx, "bucket_dir");
+        hipLaunchKernelGGL(k_bucket_dir, dim3((n_buckets + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)qk, n_q, pbits, dir_q);
+        hipLaunchKernelGGL(k_bucket_dir, dim3((n_buckets + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys, n_t, pbits, dir_t);
+        ks_timer_end(ctx);
+        SE_HIP(hipGetLastError());
 
         // join, with a retry if the match list outgrows its first guess
         SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, 1));
@@ -232,10 +269,10 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         for (int attempt = 0; attempt < 2; attempt++) {
             SE_CHECK(ks_alloc(ctx, &pk0, (size_t)cap)); SE_CHECK(ks_alloc(ctx, &pv0, (size_t)cap));
             SE_HIP(hipMemsetAsync(cursor, 0, sizeof(u64), ctx->stream));
-            ks_timer_begin(ctx, "join");
-            hipLaunchKernelGGL(k_join, dim3((u32)((n_q + JN_TILE - 1) / JN_TILE)), dim3(JN_THREADS), 0, ctx->stream,
-                               (const u64 *)qk, (const u32 *)qv, n_q, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids,
-                               (const u32 *)ix->d_abunds, n_t, pk0, pv0, cap, cursor);
+            ks_timer_begin(ctx, "join_buckets");
+            hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
+                               (const u32 *)qv, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds,
+                               (const u64 *)dir_q, (const u64 *)dir_t, pk0, pv0, cap, cursor);
             ks_timer_end(ctx);
             SE_HIP(hipGetLastError());
             SE_HIP(hipMemcpyAsync(ctx->h_pin, cursor, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
@@ -299,6 +336,7 @@ done:
     ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
     ks_pool_free(ctx, pk0); ks_pool_free(ctx, pk1); ks_pool_free(ctx, pv0); ks_pool_free(ctx, pv1);
     ks_pool_free(ctx, heads); ks_pool_free(ctx, d_nrows); ks_pool_free(ctx, row_start); ks_pool_free(ctx, cursor);
+    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, dir_t);
     if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_hits_free(H); return st; }
     *out = H;
     return KS_OK;

@@ -19,14 +19,16 @@
 //     bucket: the first arrival is the representative and carries the abundance.
 //   * Representatives are compacted through LDS and leave as one contiguous run per tile; a per-sequence
 //     count + scan + gather builds the final CSR.
-//   * Sequences longer than LS_MAX take the same algorithm with its arrays in a global scratch slab
-//     (k_sketch_long), one workgroup per sequence.
+//   * Sequences longer than LS_MAX but shorter than a tile ("medium") get a tile of their own in a second
+//     launch of the same kernel; longer ones take the same algorithm with its arrays in a global scratch
+//     slab (k_sketch_long), one workgroup per sequence.
 #include "ks_device.h"
 
 #define SK_THREADS 512
 #define SK_E 8
 #define SK_TILE (SK_THREADS * SK_E) // 4096 LDS positions
-#define SK_LS_MAX 1536              // longest sequence the tile kernel takes
+#define SK_LS_MAX 1536              // longest sequence a shared (multi-sequence) tile takes
+#define SK_MED_MAX (SK_TILE - 16)   // longest sequence that still fits one tile on its own ("medium")
 #define SK_R (SK_TILE - SK_LS_MAX - 16)
 #define SK_PAD 160                  // >= KS_MAX_KSIZE + 24: slack behind the last residue for word reads
 #define SK_NFLAG (SK_TILE / 32)
@@ -41,6 +43,9 @@ struct sk_args {
     u64 max_hash;
     u32 sfix;     // floor(2^48 / ((max_hash >> 32) + 1)): bucket multiplier = (n_windows * sfix) >> 16
     const u8 *lut; // 256-byte encode table for this moltype
+    u32 len_cap;   // sequences longer than this are not this launch's business
+    const u32 *seq_list; // NULL: tiles by residue range; else one listed (medium) sequence per workgroup
+    u64 start_flag;      // OR-ed into sp_start (marks runs that live in the lg_* buffers)
     u64 *sp_hash;  // [n_res]   tile-packed unique hashes
     u32 *sp_abund; // [n_res]
     u32 *counts;   // [n_seqs]  unique hashes per sequence
@@ -96,7 +101,7 @@ KS_DEV void sk_load_seq(sk_seq &q, const sk_args &A, u64 g0, u32 s_end) {
     q.ls = (u32)(b - g0);
     u64 le = e - g0;
     q.le = le > 0x7fffffffULL ? 0x7fffffffu : (u32)le;
-    q.nw = (len >= A.k && len <= SK_LS_MAX) ? (u32)(len - A.k + 1) : 0;
+    q.nw = (len >= A.k && len <= A.len_cap) ? (u32)(len - A.k + 1) : 0;
     q.mul = sk_bucket_mul(q.nw, A.sfix);
     q.ok = q.nw > 0;
 }
@@ -132,8 +137,12 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
     u8 *res_b = (u8 *)res_w;
 
     // ---- phase 0: tile -> sequence range (two binary searches), zero LDS state, stage the LUT
-    if (tid == 0) meta[0] = sk_lower_bound(A.offs, 0, A.n_seqs, (u64)blockIdx.x * SK_R);
-    if (tid == 64) meta[1] = sk_lower_bound(A.offs, 0, A.n_seqs, ((u64)blockIdx.x + 1) * SK_R);
+    if (A.seq_list) {
+        if (tid == 0) { u32 s = A.seq_list[blockIdx.x]; meta[0] = s; meta[1] = s + 1; }
+    } else {
+        if (tid == 0) meta[0] = sk_lower_bound(A.offs, 0, A.n_seqs, (u64)blockIdx.x * SK_R);
+        if (tid == 64) meta[1] = sk_lower_bound(A.offs, 0, A.n_seqs, ((u64)blockIdx.x + 1) * SK_R);
+    }
     if (tid < 256) lut_s[tid] = A.lut[tid];
     for (u32 i = tid; i < SK_TILE + 8; i += SK_THREADS) cnt[i] = 0;
     if (tid < SK_NFLAG) flagbits[tid] = 0;
@@ -257,13 +266,13 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
     for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
         u64 b = A.offs[s], e = A.offs[s + 1];
         u64 len = e - b;
-        if (len > SK_LS_MAX) continue; // k_sketch_long owns it
+        if (len > A.len_cap) continue; // a later launch owns it
         u32 ls = (u32)(b - g0), le = (u32)(e - g0);
         u32 x0 = cnt[ls], x1 = cnt[le];
         u32 d0 = x0 >= SK_TILE ? n_distinct : flagpre[x0 >> 5] + (u32)__popc(flagbits[x0 >> 5] & ((1u << (x0 & 31)) - 1u));
         u32 d1 = x1 >= SK_TILE ? n_distinct : flagpre[x1 >> 5] + (u32)__popc(flagbits[x1 >> 5] & ((1u << (x1 & 31)) - 1u));
         A.counts[s] = d1 - d0;
-        A.sp_start[s] = r0 + d0;
+        A.sp_start[s] = (r0 + d0) | A.start_flag;
     }
     __syncthreads();
 
@@ -307,10 +316,13 @@ struct sk_long_args {
 };
 #define SK_LONG_FLAG (1ULL << 63)
 
-__global__ __launch_bounds__(256) void k_find_long(const u64 *offs, u32 n_seqs, u32 *long_ids, u32 *n_long) {
+// n_cls[0] = medium sequences (own tile), n_cls[1] = long sequences (global-slab path)
+__global__ __launch_bounds__(256) void k_find_long(const u64 *offs, u32 n_seqs, u32 *med_ids, u32 *long_ids, u32 *n_cls) {
     u32 s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_seqs) return;
-    if (offs[s + 1] - offs[s] > SK_LS_MAX) long_ids[atomicAdd(n_long, 1u)] = s;
+    u64 len = offs[s + 1] - offs[s];
+    if (len > SK_MED_MAX) long_ids[atomicAdd(&n_cls[1], 1u)] = s;
+    else if (len > SK_LS_MAX) med_ids[atomicAdd(&n_cls[0], 1u)] = s;
 }
 
 // block-wide exclusive scan of a global u32 array in place; returns the total (uniform)
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
     const u32 tid = threadIdx.x;
     u8 *res_b = (u8 *)res_w;
     if (tid < 256) lut_s[tid] = A.lut[tid];
-    const u32 n_long = *L.n_long;
+    const u32 n_long = L.n_long[1];
     const u64 slab = (u64)blockIdx.x * ((u64)L.max_len + 1);
     u64 *keys = L.slab_keys + slab, *tmp = L.slab_tmp + slab, *sorted = L.slab_sorted + slab;
     u32 *cnt = L.slab_cnt + slab, *ord = L.slab_ord + slab, *flag = L.slab_flag + slab, *abd = L.slab_ab + slab;
@@ -461,22 +473,28 @@ __global__ __launch_bounds__(256) void k_sketch_gather(const u64 *sp_hash, const
     }
 }
 
-__global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, u32 k, u64 *out /* [0]=windows, [1]=max_len */) {
-    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-    u64 w = 0, len = 0;
-    if (s < n_seqs) {
-        len = offs[s + 1] - offs[s];
-        w = len >= k ? len - k + 1 : 0;
+// out[0] = k-mer windows, out[1] = longest sequence, out[2] = medium sequences, out[3] = long sequences
+__global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, u32 k, u64 *out) {
+    u64 w = 0, mx = 0, nm = 0, nl = 0;
+    for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n_seqs; s += gridDim.x * blockDim.x) {
+        u64 len = offs[s + 1] - offs[s];
+        w += len >= k ? len - k + 1 : 0;
+        mx = len > mx ? len : mx;
+        nl += len > SK_MED_MAX;
+        nm += (len > SK_LS_MAX) & (len <= SK_MED_MAX);
     }
-    // wave reduce then one atomic per wave
     for (int d = 32; d > 0; d >>= 1) {
         w += __shfl_down(w, d, 64);
-        u64 o = __shfl_down(len, d, 64);
-        len = o > len ? o : len;
+        nm += __shfl_down(nm, d, 64);
+        nl += __shfl_down(nl, d, 64);
+        u64 o = __shfl_down(mx, d, 64);
+        mx = o > mx ? o : mx;
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd((unsigned long long *)&out[0], (unsigned long long)w);
-        atomicMax((unsigned long long *)&out[1], (unsigned long long)len);
+        atomicMax((unsigned long long *)&out[1], (unsigned long long)mx);
+        if (nm) atomicAdd((unsigned long long *)&out[2], (unsigned long long)nm);
+        if (nl) atomicAdd((unsigned long long *)&out[3], (unsigned long long)nl);
     }
 }
 
@@ -485,6 +503,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     KS_TRY(ks_check_params(ctx, p));
     if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
     if (((uintptr_t)d_res & 15) != 0) return ks_fail(ctx, KS_ERR_INVALID_ARG, "d_residues must be 16-byte aligned");
+    (void)max_seq_len; // hint only: the real maximum is measured on the device below
     KS_HIP(ctx, hipSetDevice(ctx->device));
 
     ks_sketches *S = new ks_sketches();
@@ -497,9 +516,11 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     int st = KS_OK;
     u64 *sp_hash = nullptr, *sp_start = nullptr, *d_stats = nullptr;
     u32 *sp_abund = nullptr, *counts = nullptr;
-    u32 *long_ids = nullptr, *n_long = nullptr;
+    u32 *med_ids = nullptr, *long_ids = nullptr, *n_cls = nullptr;
     u64 *slab64 = nullptr, *lg_hash = nullptr;
     u32 *slab32 = nullptr, *lg_abund = nullptr;
+    u64 n_med = 0, n_long = 0;
+    u32 real_max = 0;
 #define SK_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
 #define SK_HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
 
@@ -513,18 +534,21 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         return KS_OK;
     }
     {
-        // windows + longest sequence (one small D2H; also validates the caller's hint)
-        SK_CHECK(ks_alloc(ctx, &d_stats, 2));
-        SK_HIPCHECK(hipMemsetAsync(d_stats, 0, 2 * sizeof(u64), ctx->stream));
+        // windows, longest sequence, medium / long counts: one small D2H
+        SK_CHECK(ks_alloc(ctx, &d_stats, 4));
+        SK_HIPCHECK(hipMemsetAsync(d_stats, 0, 4 * sizeof(u64), ctx->stream));
+        u32 g = (n_seqs + 1023) / 1024;
+        if (g > 2048) g = 2048;
         ks_timer_begin(ctx, "seq_stats");
-        hipLaunchKernelGGL(k_seq_stats, dim3((n_seqs + 255) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, p->ksize, d_stats);
+        hipLaunchKernelGGL(k_seq_stats, dim3(g), dim3(256), 0, ctx->stream, d_offs, n_seqs, p->ksize, d_stats);
         ks_timer_end(ctx);
-        SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, 4 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
         SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
         S->n_windows = ctx->h_pin[0];
-        u64 real_max = ctx->h_pin[1];
-        if (real_max > 0xfffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "sequence longer than 2^32 residues"); goto done; }
-        max_seq_len = (u32)real_max;
+        if (ctx->h_pin[1] > 0xfffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "sequence longer than 2^32 residues"); goto done; }
+        real_max = (u32)ctx->h_pin[1];
+        n_med = ctx->h_pin[2];
+        n_long = ctx->h_pin[3];
     }
 
     SK_CHECK(ks_alloc(ctx, &sp_hash, (size_t)n_res + 1));
@@ -542,6 +566,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         }
         A.lut = ctx->d_lut + 256 * p->moltype;
         A.sp_hash = sp_hash; A.sp_abund = sp_abund; A.counts = counts; A.sp_start = sp_start;
+        A.len_cap = SK_LS_MAX; A.seq_list = nullptr; A.start_flag = 0;
         const u64 n_tiles = n_res / SK_R + 1;
         if (n_tiles > 0x7fffffffULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "batch too large"); goto done; }
         ks_timer_begin(ctx, "sketch_tiles");
@@ -549,30 +574,44 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         ks_timer_end(ctx);
         SK_HIPCHECK(hipGetLastError());
 
-        if (max_seq_len > SK_LS_MAX) {
-            u64 bound = n_res / (SK_LS_MAX + 1) + 1; // upper bound on the number of long sequences
-            SK_CHECK(ks_alloc(ctx, &long_ids, (size_t)bound));
-            SK_CHECK(ks_alloc(ctx, &n_long, 1));
-            SK_HIPCHECK(hipMemsetAsync(n_long, 0, sizeof(u32), ctx->stream));
+        if (n_med + n_long > 0) {
+            // runs of medium / long sequences live in their own buffers: a shared tile's packed run may
+            // extend over the residue span of a long neighbour
+            SK_CHECK(ks_alloc(ctx, &lg_hash, (size_t)n_res + 1));
+            SK_CHECK(ks_alloc(ctx, &lg_abund, (size_t)n_res + 1));
+            SK_CHECK(ks_alloc(ctx, &med_ids, (size_t)n_med + 1));
+            SK_CHECK(ks_alloc(ctx, &long_ids, (size_t)n_long + 1));
+            SK_CHECK(ks_alloc(ctx, &n_cls, 2));
+            SK_HIPCHECK(hipMemsetAsync(n_cls, 0, 2 * sizeof(u32), ctx->stream));
             ks_timer_begin(ctx, "find_long");
-            hipLaunchKernelGGL(k_find_long, dim3((n_seqs + 255) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, long_ids, n_long);
+            hipLaunchKernelGGL(k_find_long, dim3((n_seqs + 255) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, med_ids, long_ids, n_cls);
             ks_timer_end(ctx);
+            SK_HIPCHECK(hipGetLastError());
+        }
+        if (n_med > 0) {
+            sk_args M = A;
+            M.sp_hash = lg_hash; M.sp_abund = lg_abund; M.len_cap = SK_MED_MAX; M.seq_list = med_ids;
+            M.start_flag = SK_LONG_FLAG;
+            ks_timer_begin(ctx, "sketch_medium");
+            hipLaunchKernelGGL(k_sketch_tiles, dim3((u32)n_med), dim3(SK_THREADS), 0, ctx->stream, M);
+            ks_timer_end(ctx);
+            SK_HIPCHECK(hipGetLastError());
+        }
+        if (n_long > 0) {
             // slab: 3 u64 + 4 u32 arrays of (max_len + 1) per workgroup, capped at ~2 GiB total
-            const u64 per_wg = ((u64)max_seq_len + 1) * (3 * 8 + 4 * 4);
+            const u64 stride = (u64)real_max + 1;
+            const u64 per_wg = stride * (3 * 8 + 4 * 4);
             u64 grid = (2ULL << 30) / per_wg;
             if (grid < 1) grid = 1;
-            if (grid > bound) grid = bound;
+            if (grid > n_long) grid = n_long;
             if (grid > 512) grid = 512;
-            const u64 stride = (u64)max_seq_len + 1;
             SK_CHECK(ks_alloc(ctx, &slab64, (size_t)(grid * stride * 3)));
             SK_CHECK(ks_alloc(ctx, &slab32, (size_t)(grid * stride * 4)));
             sk_long_args L;
-            L.a = A; L.long_ids = long_ids; L.n_long = n_long; L.max_len = max_seq_len;
+            L.a = A; L.long_ids = long_ids; L.n_long = n_cls; L.max_len = real_max;
             L.slab_keys = slab64; L.slab_tmp = slab64 + grid * stride; L.slab_sorted = slab64 + 2 * grid * stride;
             L.slab_cnt = slab32; L.slab_ord = slab32 + grid * stride; L.slab_flag = slab32 + 2 * grid * stride;
             L.slab_ab = slab32 + 3 * grid * stride;
-            SK_CHECK(ks_alloc(ctx, &lg_hash, (size_t)n_res + 1));
-            SK_CHECK(ks_alloc(ctx, &lg_abund, (size_t)n_res + 1));
             L.lg_hash = lg_hash; L.lg_abund = lg_abund;
             ks_timer_begin(ctx, "sketch_long");
             hipLaunchKernelGGL(k_sketch_long, dim3((u32)grid), dim3(SK_THREADS), 0, ctx->stream, L);
@@ -597,7 +636,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
 
 done:
     ks_pool_free(ctx, sp_hash); ks_pool_free(ctx, sp_abund); ks_pool_free(ctx, counts); ks_pool_free(ctx, sp_start);
-    ks_pool_free(ctx, d_stats); ks_pool_free(ctx, long_ids); ks_pool_free(ctx, n_long);
+    ks_pool_free(ctx, d_stats); ks_pool_free(ctx, med_ids); ks_pool_free(ctx, long_ids); ks_pool_free(ctx, n_cls);
     ks_pool_free(ctx, slab64); ks_pool_free(ctx, slab32); ks_pool_free(ctx, lg_hash); ks_pool_free(ctx, lg_abund);
     if (st != KS_OK) {
         (void)hipStreamSynchronize(ctx->stream);

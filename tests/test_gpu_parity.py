@@ -107,7 +107,7 @@ def test_sketch_ragged_and_edge_inputs(ctx):
     seqs = [b"", b"A", b"ACDE", b"ACDEF", b"", b"", b"plantandanimalgenqmes", b"PLANTANDANIMALGENQMES",
             b"XXXXXXXXXX", b"ACDEFXUO*BZJ", b"A" * 300, b"AC" * 700, b"W" * 5000, b"LIVINGALIVE"]
     # long sequences: just over the tile limit, mid, very long, with repeats
-    for n in (1536, 1537, 1600, 4095, 4096, 4097, 9000, 40000):
+    for n in (1536, 1537, 1600, 3000, 4079, 4080, 4081, 4095, 4096, 4097, 9000, 40000):
         seqs.append(bytes(rng.choice(aa, size=n).tolist()))
     rep = bytes(rng.choice(aa, size=500).tolist())
     seqs.append(rep * 20)  # 10k residues, every window 20x
