@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libkmerseek_amd.so")
+# KMERSEEK_AMD_LIB selects another build of the same library (kernel-tuning variants); never a fallback
+SO_PATH = os.environ.get("KMERSEEK_AMD_LIB") or os.path.join(HERE, "libkmerseek_amd.so")
 
 KS_OK = 0
 KS_ERR_INVALID_MOLTYPE = 1

@@ -28,15 +28,16 @@ def stale() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not stale():
+def build(force: bool = False, verbose: bool = False, defs=(), out: str = SO) -> str:
+    """defs: extra -D macros (kernel-tuning variants, written to `out` instead of the default .so)."""
+    if not force and not defs and out == SO and not stale():
         return SO
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [HIPCC] + FLAGS + ["-o", SO] + srcs
+    cmd = [HIPCC] + FLAGS + [f"-D{d}" for d in defs] + ["-o", out] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd, cwd=CSRC)
-    return SO
+    return out
 
 
 if __name__ == "__main__":

@@ -139,10 +139,11 @@ int ks_scan_u32_inplace(ks_ctx *ctx, u32 *data, u64 n, u32 *d_total);
 
 // LSD radix sort of (key u64, value V) on key bits [bit_lo, bit_hi), 8 bits per pass, stable.
 // Buffers ping-pong; on return *keys/*vals point at the sorted data (either input or alt).
+// `tag` names the pass family in the per-kernel timing table ("radix_scatter.<tag>").
 int ks_radix_sort_u32(ks_ctx *ctx, u64 **keys, u32 **vals, u64 *keys_alt, u32 *vals_alt, u64 n,
-                      int bit_lo, int bit_hi);
+                      int bit_lo, int bit_hi, const char *tag);
 int ks_radix_sort_u64(ks_ctx *ctx, u64 **keys, u64 **vals, u64 *keys_alt, u64 *vals_alt, u64 n,
-                      int bit_lo, int bit_hi);
+                      int bit_lo, int bit_hi, const char *tag);
 
 // ---- pipelines (ks_sketch.hip, ks_search.hip) ----
 int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,

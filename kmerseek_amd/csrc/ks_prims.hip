@@ -147,15 +147,22 @@ int ks_scan_u32_inplace(ks_ctx *ctx, u32 *data, u64 n, u32 *d_total) {
 // =============================================================================================
 // radix sort
 // =============================================================================================
-#define RS_THREADS 256
-#define RS_IPT 8
-#define RS_TILE (RS_THREADS * RS_IPT)
+#ifndef RS_THREADS
+#define RS_THREADS 512
+#endif
+#ifndef RS_IPT
+#define RS_IPT 16
+#endif
+#ifndef RS_MINW
+#define RS_MINW 2 // waves per SIMD the scatter kernel is compiled for (register budget)
+#endif
+#define RS_TILE (RS_THREADS * RS_IPT) // 8192 records: ~32 per digit, so digits leave the tile as >= 128-B runs
 #define RS_WAVES (RS_THREADS / 64)
 
 // hist[d * nblocks + block] = number of keys of this block's tile with digit d
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 *hist, u64 n, int shift, u32 nblocks) {
     __shared__ u32 bins[256];
-    bins[threadIdx.x] = 0;
+    if (threadIdx.x < 256) bins[threadIdx.x] = 0;
     __syncthreads();
     const u64 base = (u64)blockIdx.x * RS_TILE;
 #pragma unroll
@@ -164,22 +171,27 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 
         if (idx < n) atomicAdd(&bins[(u32)(keys[idx] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    hist[(u64)threadIdx.x * nblocks + blockIdx.x] = bins[threadIdx.x];
+    if (threadIdx.x < 256) hist[(u64)threadIdx.x * nblocks + blockIdx.x] = bins[threadIdx.x];
 }
 
 // Stable scatter.  Item order inside a tile is (wave, round, lane) = ascending global index, so
 // ranks computed per wave with ballot-matching + per-wave digit counters preserve input order.
+// Records are staged through ONE LDS buffer in local digit order (keys first, then values), so each
+// digit leaves the tile as a contiguous run of full cache lines.
 template <typename V>
-__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const u64 *kin, const V *vin, u64 *kout, V *vout,
+__global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64 *kin, const V *vin, u64 *kout, V *vout,
                                                               const u32 *goffs, u64 n, int shift, u32 nblocks) {
     __shared__ u32 wcnt[RS_WAVES][256];
     __shared__ u32 dstart[256];
+    __shared__ u32 gbase[256];
     __shared__ u32 scan_smem[RS_WAVES + 1];
-    __shared__ u64 skeys[RS_TILE];
-    __shared__ V svals[RS_TILE];
+    __shared__ __attribute__((aligned(16))) u64 stage[RS_TILE];
 
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int w = 0; w < RS_WAVES; w++) wcnt[w][tid] = 0;
+    if (tid < 256) {
+        for (int w = 0; w < RS_WAVES; w++) wcnt[w][tid] = 0;
+        gbase[tid] = goffs[(u64)tid * nblocks + blockIdx.x];
+    }
     __syncthreads();
 
     const u64 tile_base = (u64)blockIdx.x * RS_TILE;
@@ -193,7 +205,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const u64 *kin, co
         bool valid = idx < n;
         key[r] = valid ? kin[idx] : ~0ULL;
         val[r] = valid ? vin[idx] : (V)0;
-        u32 d = valid ? ((u32)(key[r] >> shift) & 255u) : 255u;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++) {
+        u64 idx = wbase + (u64)r * 64 + lane;
+        u32 d = idx < n ? ((u32)(key[r] >> shift) & 255u) : 255u;
         // lanes holding the same digit
         u64 peers = ~0ULL;
 #pragma unroll
@@ -210,44 +226,59 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const u64 *kin, co
         rank[r] = (d << 16) | (pre + below);
     }
     __syncthreads();
-    // digit-major exclusive offsets: thread tid owns digit tid
+    // digit-major exclusive offsets: thread d < 256 owns digit d
     {
         u32 c[RS_WAVES];
         u32 tot = 0;
+        if (tid < 256) {
 #pragma unroll
-        for (int w = 0; w < RS_WAVES; w++) { c[w] = wcnt[w][tid]; tot += c[w]; }
+            for (int w = 0; w < RS_WAVES; w++) { c[w] = wcnt[w][tid]; tot += c[w]; }
+        }
         u32 total;
         u32 ds = ks_block_excl_scan(tot, scan_smem, &total);
-        dstart[tid] = ds;
+        if (tid < 256) {
+            dstart[tid] = ds;
 #pragma unroll
-        for (int w = 0; w < RS_WAVES; w++) { wcnt[w][tid] = ds; ds += c[w]; }
+            for (int w = 0; w < RS_WAVES; w++) { wcnt[w][tid] = ds; ds += c[w]; }
+        }
     }
     __syncthreads();
+    u32 pos[RS_IPT];
 #pragma unroll
     for (int r = 0; r < RS_IPT; r++) {
-        u32 d = rank[r] >> 16;
-        u32 pos = wcnt[wave][d] + (rank[r] & 0xffffu);
-        skeys[pos] = key[r];
-        svals[pos] = val[r];
+        pos[r] = wcnt[wave][rank[r] >> 16] + (rank[r] & 0xffffu);
+        stage[pos[r]] = key[r];
     }
     __syncthreads();
     const u64 remain = n - tile_base;
     const u32 nvalid = remain < RS_TILE ? (u32)remain : RS_TILE;
+    u32 gdst[RS_IPT]; // global destination of local slot i*RS_THREADS + tid
 #pragma unroll
     for (int i = 0; i < RS_IPT; i++) {
         u32 p = (u32)i * RS_THREADS + tid;
+        gdst[i] = 0xffffffffu;
         if (p < nvalid) {
-            u64 k = skeys[p];
+            u64 k = stage[p];
             u32 d = (u32)(k >> shift) & 255u;
-            u64 g = (u64)goffs[(u64)d * nblocks + blockIdx.x] + (p - dstart[d]);
-            kout[g] = k;
-            vout[g] = svals[p];
+            gdst[i] = gbase[d] + (p - dstart[d]);
+            kout[gdst[i]] = k;
         }
+    }
+    __syncthreads();
+    V *vstage = (V *)stage;
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++) vstage[pos[r]] = val[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_IPT; i++) {
+        u32 p = (u32)i * RS_THREADS + tid;
+        if (gdst[i] != 0xffffffffu) vout[gdst[i]] = vstage[p];
     }
 }
 
 template <typename V>
-static int radix_sort_impl(ks_ctx *ctx, u64 **keys, V **vals, u64 *keys_alt, V *vals_alt, u64 n, int bit_lo, int bit_hi) {
+static int radix_sort_impl(ks_ctx *ctx, u64 **keys, V **vals, u64 *keys_alt, V *vals_alt, u64 n, int bit_lo, int bit_hi,
+                           const char *tag) {
     if (n <= 1 || bit_hi <= bit_lo) return KS_OK;
     if (n >= 0xffffffffULL) return ks_fail(ctx, KS_ERR_CAPACITY, "radix sort: %llu records exceed the 32-bit offset range", (unsigned long long)n);
     const u32 nblocks = (u32)((n + RS_TILE - 1) / RS_TILE);
@@ -257,12 +288,13 @@ static int radix_sort_impl(ks_ctx *ctx, u64 **keys, V **vals, u64 *keys_alt, V *
     V *vin = *vals, *vout = vals_alt;
     int st = KS_OK;
     for (int shift = bit_lo; shift < bit_hi && st == KS_OK; shift += 8) {
-        ks_timer_begin(ctx, "radix_hist");
+        const std::string nm_hist = std::string("radix_hist.") + tag, nm_scat = std::string("radix_scatter.") + tag;
+        ks_timer_begin(ctx, nm_hist.c_str());
         hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)kin, hist, n, shift, nblocks);
         ks_timer_end(ctx);
         st = ks_scan_u32_inplace(ctx, hist, (u64)256 * nblocks, nullptr);
         if (st != KS_OK) break;
-        ks_timer_begin(ctx, sizeof(V) == 4 ? "radix_scatter_v32" : "radix_scatter_v64");
+        ks_timer_begin(ctx, nm_scat.c_str());
         hipLaunchKernelGGL((k_radix_scatter<V>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)kin,
                            (const V *)vin, kout, vout, (const u32 *)hist, n, shift, nblocks);
         ks_timer_end(ctx);
@@ -276,9 +308,11 @@ static int radix_sort_impl(ks_ctx *ctx, u64 **keys, V **vals, u64 *keys_alt, V *
     return st;
 }
 
-int ks_radix_sort_u32(ks_ctx *ctx, u64 **keys, u32 **vals, u64 *keys_alt, u32 *vals_alt, u64 n, int bit_lo, int bit_hi) {
-    return radix_sort_impl<u32>(ctx, keys, vals, keys_alt, vals_alt, n, bit_lo, bit_hi);
+int ks_radix_sort_u32(ks_ctx *ctx, u64 **keys, u32 **vals, u64 *keys_alt, u32 *vals_alt, u64 n, int bit_lo, int bit_hi,
+                      const char *tag) {
+    return radix_sort_impl<u32>(ctx, keys, vals, keys_alt, vals_alt, n, bit_lo, bit_hi, tag);
 }
-int ks_radix_sort_u64(ks_ctx *ctx, u64 **keys, u64 **vals, u64 *keys_alt, u64 *vals_alt, u64 n, int bit_lo, int bit_hi) {
-    return radix_sort_impl<u64>(ctx, keys, vals, keys_alt, vals_alt, n, bit_lo, bit_hi);
+int ks_radix_sort_u64(ks_ctx *ctx, u64 **keys, u64 **vals, u64 *keys_alt, u64 *vals_alt, u64 n, int bit_lo, int bit_hi,
+                      const char *tag) {
+    return radix_sort_impl<u64>(ctx, keys, vals, keys_alt, vals_alt, n, bit_lo, bit_hi, tag);
 }

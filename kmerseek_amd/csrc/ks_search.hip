@@ -66,7 +66,7 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
         ks_timer_end(ctx);
         IX_HIP(hipGetLastError());
         u64 *ks = k0, *vs = v0;
-        IX_CHECK(ks_radix_sort_u64(ctx, &ks, &vs, k1, v1, n, 0, 64));
+        IX_CHECK(ks_radix_sort_u64(ctx, &ks, &vs, k1, v1, n, 0, 64, "index"));
         ks_timer_begin(ctx, "split_vals");
         hipLaunchKernelGGL(k_split_vals, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u64 *)vs, n, ix->d_tids, ix->d_abunds);
         ks_timer_end(ctx);
@@ -96,8 +96,17 @@ done:
 // binary-searches them there, and each match is appended to the pair list through an atomic cursor.
 // Buckets larger than the LDS stage (heavy duplicate hashes) are walked in chunks.
 // ---------------------------------------------------------------------------------------------
-#define JN_THREADS 256
-#define JN_CAP 6144 // index keys staged per chunk: 48 KiB of LDS -> 3 workgroups per CU
+#ifndef JN_THREADS
+#define JN_THREADS 512
+#endif
+#ifndef JN_E
+#define JN_E 12
+#endif
+//                     JN_E query postings per thread per round: 12 independent fixed-trip LDS searches in flight
+#ifndef JN_CAP
+#define JN_CAP 6144
+#endif
+//                          index keys staged per chunk: 48 KiB of LDS -> 3 workgroups (24 waves) per CU
 
 // dir[b] = first posting whose top `pbits` bits are >= b, for b in [0, 2^pbits]; keys are ordered on those bits
 __global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int pbits, u64 *dir) {
@@ -115,19 +124,23 @@ __global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int 
     dir[b] = lo;
 }
 
+// number of staged keys < h: branchless, fixed 13 probes (n <= JN_CAP < 8192), so the JN_E searches of a
+// thread are independent instruction streams the scheduler can interleave
 KS_DEV u32 jn_lower_bound_lds(const u64 *lk, u32 n, u64 h) {
-    u32 lo = 0, hi = n;
-    while (lo < hi) {
-        u32 mid = (lo + hi) >> 1;
-        if (lk[mid] < h) lo = mid + 1; else hi = mid;
+    u32 pos = 0;
+#pragma unroll
+    for (u32 step = 4096; step > 0; step >>= 1) {
+        const u32 t = pos + step;
+        const u32 idx = t <= n ? t - 1 : n - 1;
+        const u64 v = lk[idx];
+        pos = (t <= n && v < h) ? t : pos;
     }
-    return lo;
+    return pos;
 }
 
 // cursor[0] = matches appended so far (keeps counting past `cap` so the host can size a retry).
-// Two passes per staged chunk: count matches per thread, reserve the workgroup's slice of the pair list
-// with ONE global atomic, then search again and write (an LDS search is far cheaper than a contended
-// device-wide atomic per match).
+// Per round of JN_THREADS*JN_E query postings: search once, keep (position, run length) in registers,
+// reserve the round's slice of the pair list with ONE device-wide atomic, then write from registers.
 __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, const u32 *qids, const u64 *ikeys,
                                                              const u32 *itids, const u32 *iabunds, const u64 *dir_q,
                                                              const u64 *dir_t, u64 *pair_keys, u32 *pair_vals, u64 cap,
@@ -143,34 +156,47 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
         const u32 n = (u32)((te - c0) < JN_CAP ? (te - c0) : JN_CAP);
         for (u32 i = tid; i < n; i += JN_THREADS) lk[i] = ikeys[c0 + i];
         __syncthreads();
-        u32 mine = 0;
-        for (u64 i = qs + tid; i < qe; i += JN_THREADS) {
-            const u64 h = qkeys[i];
-            u32 lo = jn_lower_bound_lds(lk, n, h);
-            while (lo < n && lk[lo] == h) { mine++; lo++; }
-        }
-        u32 total;
-        const u32 off = ks_block_excl_scan(mine, scan_smem, &total);
-        if (total) { // uniform
-            if (tid == 0) base_s = atomicAdd(cursor, (unsigned long long)total);
-            __syncthreads();
-            u64 slot = base_s + off;
-            if (mine) {
-                for (u64 i = qs + tid; i < qe; i += JN_THREADS) {
-                    const u64 h = qkeys[i];
-                    u32 lo = jn_lower_bound_lds(lk, n, h);
-                    if (lo < n && lk[lo] == h) {
+        for (u64 q0 = qs; q0 < qe; q0 += (u64)JN_THREADS * JN_E) {
+            u64 h[JN_E];
+            u32 info[JN_E]; // position | run length << 16
+#pragma unroll
+            for (int e = 0; e < JN_E; e++) {
+                const u64 i = q0 + (u64)e * JN_THREADS + tid;
+                h[e] = i < qe ? qkeys[i] : 0;
+            }
+            u32 mine = 0;
+#pragma unroll
+            for (int e = 0; e < JN_E; e++) {
+                const u64 i = q0 + (u64)e * JN_THREADS + tid;
+                u32 lo = jn_lower_bound_lds(lk, n, h[e]);
+                u32 c = 0;
+                if (i < qe)
+                    while (lo + c < n && lk[lo + c] == h[e]) c++;
+                info[e] = lo | (c << 16);
+                mine += c;
+            }
+            u32 total;
+            const u32 off = ks_block_excl_scan(mine, scan_smem, &total);
+            if (total) { // uniform
+                if (tid == 0) base_s = atomicAdd(cursor, (unsigned long long)total);
+                __syncthreads();
+                u64 slot = base_s + off;
+#pragma unroll
+                for (int e = 0; e < JN_E; e++) {
+                    const u32 c = info[e] >> 16;
+                    if (c) {
+                        const u64 i = q0 + (u64)e * JN_THREADS + tid;
                         const u32 q = qids[i];
-                        do {
+                        const u64 j0 = c0 + (info[e] & 0xffffu);
+                        for (u32 j = 0; j < c; j++, slot++) {
                             if (slot < cap) {
-                                pair_keys[slot] = ((u64)q << 32) | itids[c0 + lo];
-                                pair_vals[slot] = iabunds[c0 + lo];
+                                pair_keys[slot] = ((u64)q << 32) | itids[j0 + j];
+                                pair_vals[slot] = iabunds[j0 + j];
                             }
-                            slot++;
-                            lo++;
-                        } while (lo < n && lk[lo] == h);
+                        }
                     }
                 }
+                __syncthreads(); // base_s is rewritten next round
             }
         }
         __syncthreads();
@@ -252,7 +278,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         // buckets of ~3k index postings; the query side is partitioned (not sorted) on the same top bits
         int pbits = 0;
         while (pbits < 16 && (n_t >> pbits) > 3072) pbits++;
-        SE_CHECK(ks_radix_sort_u32(ctx, &qk, &qv, qk1, qv1, n_q, 64 - pbits, 64));
+        SE_CHECK(ks_radix_sort_u32(ctx, &qk, &qv, qk1, qv1, n_q, 64 - pbits, 64, "qpart"));
         const u32 n_buckets = 1u << pbits;
         SE_CHECK(ks_alloc(ctx, &dir_q, (size_t)n_buckets + 1));
         SE_CHECK(ks_alloc(ctx, &dir_t, (size_t)n_buckets + 1));
@@ -300,11 +326,11 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         u64 *pk = pk0;
         u32 *pv = pv0;
         const int tb = (bits_for(ix->n_targets) + 7) / 8 * 8, qb = (bits_for(q->n_seqs) + 7) / 8 * 8;
-        SE_CHECK(ks_radix_sort_u32(ctx, &pk, &pv, pk1, pv1, n_pairs, 0, tb));
+        SE_CHECK(ks_radix_sort_u32(ctx, &pk, &pv, pk1, pv1, n_pairs, 0, tb, "pairs"));
         {
             u64 *alt_k = (pk == pk0) ? pk1 : pk0;
             u32 *alt_v = (pv == pv0) ? pv1 : pv0;
-            SE_CHECK(ks_radix_sort_u32(ctx, &pk, &pv, alt_k, alt_v, n_pairs, 32, 32 + qb));
+            SE_CHECK(ks_radix_sort_u32(ctx, &pk, &pv, alt_k, alt_v, n_pairs, 32, 32 + qb, "pairs"));
         }
         // run-length reduce
         SE_CHECK(ks_alloc(ctx, &heads, (size_t)n_pairs));
