@@ -175,34 +175,34 @@ def main():
         # sketch: L residues read + 12 B per unique kept hash written + 8 B offset per sequence
         "sketch_tiles": n_q_res + 12 * n_q_hashes + 8 * args.queries,
         "sketch_gather": 24 * n_q_hashes,
-        # one radix pass moves each (hash u64, qid u32) posting once in, once out
-        "radix_scatter_v32": 24 * n_q_hashes,
-        "radix_hist": 8 * n_q_hashes,
+        # one partition pass moves each (hash u64, qid u32) posting once in, once out
+        "radix_scatter.qpart": 24 * n_q_hashes,
+        "radix_hist.qpart": 8 * n_q_hashes,
         # join: 12 B per query posting + 12 B per index posting read once + 16 B per emitted pair
         "join_buckets": 12 * n_q_hashes + 12 * n_t_postings + 16 * n_pairs,
     }
     per_kernel = {name: {"launches": n, "avg_ms": (ms / n if n else 0.0), "total_ms": ms}
                   for name, (n, ms) in timing.items()}
-    dom = max(timing.items(), key=lambda kv: kv[1][1])[0] if timing else None
-    roofline = None
-    if dom is not None:
-        n_l, ms = timing[dom]
+    def roof(name):
+        n_l, ms = timing[name]
         avg_s = ms / n_l / 1e3
-        b = algo_bytes.get(dom)
-        if dom == "radix_scatter_v32":
-            # launches mix the query sort (N_Q postings) and the much smaller match sort: quote the query passes
-            b = 24 * n_q_hashes
+        b = algo_bytes.get(name)
         ach = (b / avg_s / 1e9) if (b and avg_s > 0) else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom)
-            except Exception:
-                traffic = None
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": b, "avg_launch_ms": avg_s * 1e3}
+        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic_tab.get(name),
+                "algorithmic_bytes_per_launch": b, "avg_launch_ms": avg_s * 1e3, "launches_per_step": n_l / args.steps}
+
+    traffic_tab = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic_tab = json.load(open(tpath)).get("per_launch_bytes", {})
+        except Exception:
+            traffic_tab = {}
+    # dominant kernel = largest share of the timed region (sum over its launches)
+    dom = max(timing.items(), key=lambda kv: kv[1][1])[0] if timing else None
+    roofline = roof(dom) if dom else None
+    roofline_others = [roof(n) for n in algo_bytes if n in timing and n != dom]
 
     # ---- CPU baseline: the oracle (C restatement of the reference CPU path) on a bounded sample, rank 0, N=1 only
     cpu = None
@@ -254,7 +254,7 @@ def main():
         "query_windows_per_gpu": q_windows, "query_hashes": n_q_hashes, "index_postings": n_t_postings,
         "hits": all_hits, "matched_posting_pairs": n_pairs,
         "index_build_s": index_build_s, "datagen_s": gen_s,
-        "roofline": roofline, "cpu_baseline": cpu, "kernels": per_kernel,
+        "roofline": roofline, "cpu_baseline": cpu, "roofline_other_kernels": roofline_others, "kernels": per_kernel,
     }
     print(json.dumps(result))
     ctx.close()

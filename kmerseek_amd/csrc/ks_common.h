@@ -137,13 +137,15 @@ int ks_scan_u32_to_u64(ks_ctx *ctx, const u32 *in, u64 *out, u64 n);
 // exclusive scan u32 -> u32 in place (n < 2^32 total); optionally writes the total to d_total
 int ks_scan_u32_inplace(ks_ctx *ctx, u32 *data, u64 n, u32 *d_total);
 
-// LSD radix sort of (key u64, value V) on key bits [bit_lo, bit_hi), 8 bits per pass, stable.
-// Buffers ping-pong; on return *keys/*vals point at the sorted data (either input or alt).
-// `tag` names the pass family in the per-kernel timing table ("radix_scatter.<tag>").
-int ks_radix_sort_u32(ks_ctx *ctx, u64 **keys, u32 **vals, u64 *keys_alt, u32 *vals_alt, u64 n,
-                      int bit_lo, int bit_hi, const char *tag);
-int ks_radix_sort_u64(ks_ctx *ctx, u64 **keys, u64 **vals, u64 *keys_alt, u64 *vals_alt, u64 n,
-                      int bit_lo, int bit_hi, const char *tag);
+// Stable LSD radix passes over (key u64, value V) records, one 8-bit digit at each listed shift.
+// keys_in / vals_in are only read (they may be the caller's own data, or one of the scratch pairs);
+// passes ping-pong between the scratch pairs (ka, va) and (kb, vb); *keys_out / *vals_out point at the
+// result.  `tag` picks the kernel instantiation name ("radix_scatter.<tag>" in the timing table).
+enum { KS_SORT_INDEX = 0, KS_SORT_QPART = 1, KS_SORT_PAIRS = 2 };
+int ks_radix_sort_u32(ks_ctx *ctx, int tag, const u64 *keys_in, const u32 *vals_in, u64 *ka, u32 *va, u64 *kb, u32 *vb,
+                      u64 n, const int *shifts, int n_shifts, u64 **keys_out, u32 **vals_out);
+int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_in, u64 *ka, u64 *va, u64 *kb, u64 *vb,
+                      u64 n, const int *shifts, int n_shifts, u64 **keys_out, u64 **vals_out);
 
 // ---- pipelines (ks_sketch.hip, ks_search.hip) ----
 int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,

@@ -159,7 +159,10 @@ int ks_scan_u32_inplace(ks_ctx *ctx, u32 *data, u64 n, u32 *d_total) {
 #define RS_TILE (RS_THREADS * RS_IPT) // 8192 records: ~32 per digit, so digits leave the tile as >= 128-B runs
 #define RS_WAVES (RS_THREADS / 64)
 
+// TAG only gives the instantiations of one kernel distinct names per use (index build / query
+// partition / match sort), so profiler rows and the library's own HIP-event table line up.
 // hist[d * nblocks + block] = number of keys of this block's tile with digit d
+template <int TAG>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 *hist, u64 n, int shift, u32 nblocks) {
     __shared__ u32 bins[256];
     if (threadIdx.x < 256) bins[threadIdx.x] = 0;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 
 // ranks computed per wave with ballot-matching + per-wave digit counters preserve input order.
 // Records are staged through ONE LDS buffer in local digit order (keys first, then values), so each
 // digit leaves the tile as a contiguous run of full cache lines.
-template <typename V>
+template <typename V, int TAG>
 __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64 *kin, const V *vin, u64 *kout, V *vout,
                                                               const u32 *goffs, u64 n, int shift, u32 nblocks) {
     __shared__ u32 wcnt[RS_WAVES][256];
@@ -276,43 +279,55 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
     }
 }
 
-template <typename V>
-static int radix_sort_impl(ks_ctx *ctx, u64 **keys, V **vals, u64 *keys_alt, V *vals_alt, u64 n, int bit_lo, int bit_hi,
-                           const char *tag) {
-    if (n <= 1 || bit_hi <= bit_lo) return KS_OK;
+static const char *const rs_tag_names[3] = {"index", "qpart", "pairs"};
+
+template <typename V, int TAG>
+static int radix_sort_tagged(ks_ctx *ctx, const u64 *keys_in, const V *vals_in, u64 *ka, V *va, u64 *kb, V *vb, u64 n,
+                             const int *shifts, int n_shifts, u64 **keys_out, V **vals_out) {
+    *keys_out = (u64 *)keys_in;
+    *vals_out = (V *)vals_in;
+    if (n <= 1 || n_shifts <= 0) return KS_OK;
     if (n >= 0xffffffffULL) return ks_fail(ctx, KS_ERR_CAPACITY, "radix sort: %llu records exceed the 32-bit offset range", (unsigned long long)n);
     const u32 nblocks = (u32)((n + RS_TILE - 1) / RS_TILE);
     u32 *hist = nullptr;
     KS_TRY(ks_alloc(ctx, &hist, (size_t)256 * nblocks));
-    u64 *kin = *keys, *kout = keys_alt;
-    V *vin = *vals, *vout = vals_alt;
+    const std::string nm_hist = std::string("radix_hist.") + rs_tag_names[TAG], nm_scat = std::string("radix_scatter.") + rs_tag_names[TAG];
+    const u64 *kin = keys_in;
+    const V *vin = vals_in;
+    // the caller's input is only ever read; passes ping-pong between the two scratch pairs
+    bool to_a = (keys_in != ka);
     int st = KS_OK;
-    for (int shift = bit_lo; shift < bit_hi && st == KS_OK; shift += 8) {
-        const std::string nm_hist = std::string("radix_hist.") + tag, nm_scat = std::string("radix_scatter.") + tag;
+    for (int i = 0; i < n_shifts && st == KS_OK; i++) {
+        u64 *kout = to_a ? ka : kb;
+        V *vout = to_a ? va : vb;
         ks_timer_begin(ctx, nm_hist.c_str());
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)kin, hist, n, shift, nblocks);
+        hipLaunchKernelGGL((k_radix_hist<TAG>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, kin, hist, n, shifts[i], nblocks);
         ks_timer_end(ctx);
         st = ks_scan_u32_inplace(ctx, hist, (u64)256 * nblocks, nullptr);
         if (st != KS_OK) break;
         ks_timer_begin(ctx, nm_scat.c_str());
-        hipLaunchKernelGGL((k_radix_scatter<V>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)kin,
-                           (const V *)vin, kout, vout, (const u32 *)hist, n, shift, nblocks);
+        hipLaunchKernelGGL((k_radix_scatter<V, TAG>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, kin, vin, kout, vout,
+                           (const u32 *)hist, n, shifts[i], nblocks);
         ks_timer_end(ctx);
         if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "radix sort launch failed");
-        u64 *tk = kin; kin = kout; kout = tk;
-        V *tv = vin; vin = vout; vout = tv;
+        kin = kout;
+        vin = vout;
+        to_a = !to_a;
     }
     ks_pool_free(ctx, hist);
-    *keys = kin;
-    *vals = vin;
+    *keys_out = (u64 *)kin;
+    *vals_out = (V *)vin;
     return st;
 }
 
-int ks_radix_sort_u32(ks_ctx *ctx, u64 **keys, u32 **vals, u64 *keys_alt, u32 *vals_alt, u64 n, int bit_lo, int bit_hi,
-                      const char *tag) {
-    return radix_sort_impl<u32>(ctx, keys, vals, keys_alt, vals_alt, n, bit_lo, bit_hi, tag);
+int ks_radix_sort_u32(ks_ctx *ctx, int tag, const u64 *keys_in, const u32 *vals_in, u64 *ka, u32 *va, u64 *kb, u32 *vb, u64 n,
+                      const int *shifts, int n_shifts, u64 **keys_out, u32 **vals_out) {
+    if (tag == KS_SORT_QPART)
+        return radix_sort_tagged<u32, KS_SORT_QPART>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out);
+    return radix_sort_tagged<u32, KS_SORT_PAIRS>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out);
 }
-int ks_radix_sort_u64(ks_ctx *ctx, u64 **keys, u64 **vals, u64 *keys_alt, u64 *vals_alt, u64 n, int bit_lo, int bit_hi,
-                      const char *tag) {
-    return radix_sort_impl<u64>(ctx, keys, vals, keys_alt, vals_alt, n, bit_lo, bit_hi, tag);
+int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_in, u64 *ka, u64 *va, u64 *kb, u64 *vb, u64 n,
+                      const int *shifts, int n_shifts, u64 **keys_out, u64 **vals_out) {
+    (void)tag;
+    return radix_sort_tagged<u64, KS_SORT_INDEX>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out);
 }

@@ -59,14 +59,16 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
     IX_CHECK(ks_alloc(ctx, &ix->d_tids, (size_t)n));
     IX_CHECK(ks_alloc(ctx, &ix->d_abunds, (size_t)n));
     if (n > 0) {
-        IX_HIP(hipMemcpyAsync(k0, t->d_hashes, (size_t)n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+        // values = (abund << 32 | tid) in v0; keys are read straight from the sketches on the first pass
         ks_timer_begin(ctx, "fill_index_vals");
         hipLaunchKernelGGL(k_fill_index_vals, dim3((t->n_seqs + 3) / 4), dim3(256), 0, ctx->stream, (const u64 *)t->d_offsets,
                            (const u32 *)t->d_abunds, t->n_seqs, v0);
         ks_timer_end(ctx);
         IX_HIP(hipGetLastError());
-        u64 *ks = k0, *vs = v0;
-        IX_CHECK(ks_radix_sort_u64(ctx, &ks, &vs, k1, v1, n, 0, 64, "index"));
+        const int shifts[8] = {0, 8, 16, 24, 32, 40, 48, 56};
+        u64 *ks = nullptr, *vs = nullptr;
+        // v0 holds the input values, so the first pass must land in (k1, v1): pass it as the "a" pair
+        IX_CHECK(ks_radix_sort_u64(ctx, KS_SORT_INDEX, t->d_hashes, v0, k1, v1, k0, v0, n, shifts, 8, &ks, &vs));
         ks_timer_begin(ctx, "split_vals");
         hipLaunchKernelGGL(k_split_vals, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u64 *)vs, n, ix->d_tids, ix->d_abunds);
         ks_timer_end(ctx);
@@ -268,17 +270,22 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         // query postings
         SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qk1, (size_t)n_q));
         SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qv1, (size_t)n_q));
-        SE_HIP(hipMemcpyAsync(qk0, q->d_hashes, (size_t)n_q * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
         ks_timer_begin(ctx, "fill_query_vals");
         hipLaunchKernelGGL(k_fill_query_vals, dim3((q->n_seqs + 3) / 4), dim3(256), 0, ctx->stream, (const u64 *)q->d_offsets, q->n_seqs, qv0);
         ks_timer_end(ctx);
         SE_HIP(hipGetLastError());
-        u64 *qk = qk0;
-        u32 *qv = qv0;
+        u64 *qk = nullptr;
+        u32 *qv = nullptr;
         // buckets of ~3k index postings; the query side is partitioned (not sorted) on the same top bits
         int pbits = 0;
         while (pbits < 16 && (n_t >> pbits) > 3072) pbits++;
-        SE_CHECK(ks_radix_sort_u32(ctx, &qk, &qv, qk1, qv1, n_q, 64 - pbits, 64, "qpart"));
+        {
+            // hashes are read straight from the query sketches on the first pass (no staging copy);
+            // qv0 holds the input qids, so the first pass lands in (qk1, qv1)
+            int shifts[2], ns = 0;
+            for (int sh = 64 - pbits; sh < 64; sh += 8) shifts[ns++] = sh;
+            SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_QPART, q->d_hashes, qv0, qk1, qv1, qk0, qv0, n_q, shifts, ns, &qk, &qv));
+        }
         const u32 n_buckets = 1u << pbits;
         SE_CHECK(ks_alloc(ctx, &dir_q, (size_t)n_buckets + 1));
         SE_CHECK(ks_alloc(ctx, &dir_t, (size_t)n_buckets + 1));
@@ -323,14 +330,15 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         }
         // sort matches by (qid, tid) on the live id bits only
         SE_CHECK(ks_alloc(ctx, &pk1, (size_t)n_pairs)); SE_CHECK(ks_alloc(ctx, &pv1, (size_t)n_pairs));
-        u64 *pk = pk0;
-        u32 *pv = pv0;
-        const int tb = (bits_for(ix->n_targets) + 7) / 8 * 8, qb = (bits_for(q->n_seqs) + 7) / 8 * 8;
-        SE_CHECK(ks_radix_sort_u32(ctx, &pk, &pv, pk1, pv1, n_pairs, 0, tb, "pairs"));
+        u64 *pk = nullptr;
+        u32 *pv = nullptr;
         {
-            u64 *alt_k = (pk == pk0) ? pk1 : pk0;
-            u32 *alt_v = (pv == pv0) ? pv1 : pv0;
-            SE_CHECK(ks_radix_sort_u32(ctx, &pk, &pv, alt_k, alt_v, n_pairs, 32, 32 + qb, "pairs"));
+            const int tb = (bits_for(ix->n_targets) + 7) / 8 * 8, qb = (bits_for(q->n_seqs) + 7) / 8 * 8;
+            int shifts[8], ns = 0;
+            for (int sh = 0; sh < tb; sh += 8) shifts[ns++] = sh;
+            for (int sh = 32; sh < 32 + qb; sh += 8) shifts[ns++] = sh;
+            // the match list (pk0, pv0) is scratch from here on: ping-pong with (pk1, pv1)
+            SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_PAIRS, pk0, pv0, pk0, pv0, pk1, pv1, n_pairs, shifts, ns, &pk, &pv));
         }
         // run-length reduce
         SE_CHECK(ks_alloc(ctx, &heads, (size_t)n_pairs));

@@ -123,6 +123,8 @@ KS_DEV void sk_do_window(const sk_args &A, const u64 *wl, u32 q0, sk_seq &q, u64
     bo_out = bo;
 }
 
+// MODE 0: shared tiles cut by residue range; MODE 1: one listed medium sequence per workgroup
+template <int MODE>
 __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
     __shared__ __attribute__((aligned(16))) u64 res_w[(SK_TILE + SK_PAD) / 8];
     __shared__ __attribute__((aligned(16))) u32 cnt[SK_TILE + 8];
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
     u8 *res_b = (u8 *)res_w;
 
     // ---- phase 0: tile -> sequence range (two binary searches), zero LDS state, stage the LUT
-    if (A.seq_list) {
+    if (MODE == 1) {
         if (tid == 0) { u32 s = A.seq_list[blockIdx.x]; meta[0] = s; meta[1] = s + 1; }
     } else {
         if (tid == 0) meta[0] = sk_lower_bound(A.offs, 0, A.n_seqs, (u64)blockIdx.x * SK_R);
@@ -570,7 +572,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         const u64 n_tiles = n_res / SK_R + 1;
         if (n_tiles > 0x7fffffffULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "batch too large"); goto done; }
         ks_timer_begin(ctx, "sketch_tiles");
-        hipLaunchKernelGGL(k_sketch_tiles, dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
+        hipLaunchKernelGGL(k_sketch_tiles<0>, dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
         ks_timer_end(ctx);
         SK_HIPCHECK(hipGetLastError());
 
@@ -593,7 +595,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             M.sp_hash = lg_hash; M.sp_abund = lg_abund; M.len_cap = SK_MED_MAX; M.seq_list = med_ids;
             M.start_flag = SK_LONG_FLAG;
             ks_timer_begin(ctx, "sketch_medium");
-            hipLaunchKernelGGL(k_sketch_tiles, dim3((u32)n_med), dim3(SK_THREADS), 0, ctx->stream, M);
+            hipLaunchKernelGGL(k_sketch_tiles<1>, dim3((u32)n_med), dim3(SK_THREADS), 0, ctx->stream, M);
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
         }
