@@ -33,6 +33,23 @@
 #define SK_PAD 160                  // >= KS_MAX_KSIZE + 24: slack behind the last residue for word reads
 #define SK_NFLAG (SK_TILE / 32)
 
+// Diagnostic build only (-DSK_STAMP): per-phase shader-clock shares of k_sketch_tiles, summed over
+// workgroups by lane 0.  Never compiled into the shipped library; the numbers are shares, not times.
+#ifdef SK_STAMP
+#define SK_STAMP_SLOTS 4096
+__device__ unsigned long long sk_stamp_acc[SK_STAMP_SLOTS][16];
+#define SK_STAMP_AT(i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); \
+    atomicAdd(&sk_stamp_acc[blockIdx.x % SK_STAMP_SLOTS][i], t_ - sk_t_prev); sk_t_prev = clock64(); } } while (0)
+extern "C" void ks_debug_read_stamps(unsigned long long *out, int reset) {
+    static unsigned long long host[SK_STAMP_SLOTS][16];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(sk_stamp_acc), sizeof host);
+    for (int i = 0; i < 16; i++) { out[i] = 0; for (int s = 0; s < SK_STAMP_SLOTS; s++) out[i] += host[s][i]; }
+    if (reset) { memset(host, 0, sizeof host); (void)hipMemcpyToSymbol(HIP_SYMBOL(sk_stamp_acc), host, sizeof host); }
+}
+#else
+#define SK_STAMP_AT(i) do { } while (0)
+#endif
+
 struct sk_args {
     const u8 *res;
     const u64 *offs;
@@ -44,7 +61,7 @@ struct sk_args {
     u32 sfix;     // floor(2^48 / ((max_hash >> 32) + 1)): bucket multiplier = (n_windows * sfix) >> 16
     const u8 *lut; // 256-byte encode table for this moltype
     u32 len_cap;   // sequences longer than this are not this launch's business
-    const u32 *seq_list; // NULL: tiles by residue range; else one listed (medium) sequence per workgroup
+    const u32 *seq_list; // MODE 0: tile_first[n_tiles + 1] (tile -> first sequence); MODE 1: one medium sequence per workgroup
     u64 start_flag;      // OR-ed into sp_start (marks runs that live in the lg_* buffers)
     u64 *sp_hash;  // [n_res]   tile-packed unique hashes
     u32 *sp_abund; // [n_res]
@@ -86,41 +103,60 @@ KS_DEV u64 sk_hash_window(const u64 *w /* LDS words starting at pos8 */, u32 k, 
     return m.finish((u64)k);
 }
 
+#define SK_SEQ_CAP 510 // sequence boundaries of a tile staged in LDS (tiles with more fall back to global reads)
+
+// Sequence boundaries of the tile in LOCAL coordinates (byte position relative to g0, clamped to 2^31-1),
+// served from LDS when the tile has <= SK_SEQ_CAP sequences, else straight from the offsets array.
+struct sk_bounds {
+    const u32 *loff; // LDS copy, entry i = local offset of sequence s_first + i (ns + 1 entries)
+    const u64 *goff; // global offsets
+    u64 g0;
+    u32 s_first;
+    bool in_lds;
+    KS_DEV u32 at(u32 s) const {
+        if (in_lds) return loff[s - s_first];
+        u64 v = goff[s] - g0;
+        return v > 0x7fffffffULL ? 0x7fffffffu : (u32)v;
+    }
+};
+
 struct sk_seq { // per-thread view of the sequence its current window belongs to
     u32 s;      // sequence id
     u32 ls, le; // local [start, end) in tile coordinates (le clamped)
     u32 nw;     // windows
     u32 mul;    // bucket multiplier
-    bool ok;    // short enough for the tile kernel and has windows
+    bool ok;    // short enough for this launch and has windows
 };
 
-KS_DEV void sk_load_seq(sk_seq &q, const sk_args &A, u64 g0, u32 s_end) {
+KS_DEV void sk_load_seq(sk_seq &q, const sk_args &A, const sk_bounds &B, u32 s_end) {
     if (q.s >= s_end) { q.ok = false; q.ls = 0xffffffffu; q.le = 0xffffffffu; q.nw = 0; q.mul = 0; return; }
-    u64 b = A.offs[q.s], e = A.offs[q.s + 1];
-    u64 len = e - b;
-    q.ls = (u32)(b - g0);
-    u64 le = e - g0;
-    q.le = le > 0x7fffffffULL ? 0x7fffffffu : (u32)le;
-    q.nw = (len >= A.k && len <= A.len_cap) ? (u32)(len - A.k + 1) : 0;
+    q.ls = B.at(q.s);
+    q.le = B.at(q.s + 1);
+    const u32 len = q.le - q.ls; // a clamped end only makes a too-long sequence look (still) too long
+    q.nw = (len >= A.k && len <= A.len_cap) ? (len - A.k + 1) : 0;
     q.mul = sk_bucket_mul(q.nw, A.sfix);
     q.ok = q.nw > 0;
 }
 
-template <int I>
-KS_DEV void sk_do_window(const sk_args &A, const u64 *wl, u32 q0, sk_seq &q, u64 g0, u32 s_end, u32 *cnt,
-                         u64 &h_out, u32 &bo_out) {
-    const u32 p = q0 + I;
-    while (q.s < s_end && p >= q.le) { q.s++; sk_load_seq(q, A, g0, s_end); }
-    u64 h = sk_hash_window<I>(wl, A.k, A.seed);
-    bool keep = q.ok && p >= q.ls && p + A.k <= q.le && h != 0 && h <= A.max_hash;
+// bookkeeping for the window at local position p: which sequence, is it a real window, bucket + arrival slot
+KS_DEV u32 sk_place_window(const sk_args &A, u32 p, u64 h, sk_seq &q, const sk_bounds &B, u32 s_end, u32 *cnt) {
+    while (q.s < s_end && p >= q.le) { q.s++; sk_load_seq(q, A, B, s_end); }
+    const bool keep = q.ok && p >= q.ls && p + A.k <= q.le && h != 0 && h <= A.max_hash;
     u32 bo = 0xffffffffu;
     if (keep) {
-        u32 b = q.ls + __umulhi((u32)(h >> 32), q.mul);
-        u32 o = atomicAdd(&cnt[b], 1u);
+        const u32 b = q.ls + __umulhi((u32)(h >> 32), q.mul);
+        const u32 o = atomicAdd(&cnt[b], 1u);
         bo = (b << 16) | o; // b < 4096, o < 4096
     }
-    h_out = h;
-    bo_out = bo;
+    return bo;
+}
+
+// tile_first[t] = first sequence whose start offset is >= t * SK_R (n_tiles + 1 entries): one parallel
+// binary search per tile here instead of a serial, latency-bound one at the head of every workgroup
+__global__ __launch_bounds__(256) void k_tile_plan(const u64 *offs, u32 n_seqs, u32 n_tiles, u32 *tile_first) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    tile_first[t] = t == n_tiles ? n_seqs : sk_lower_bound(offs, 0, n_seqs, (u64)t * SK_R);
 }
 
 // MODE 0: shared tiles cut by residue range; MODE 1: one listed medium sequence per workgroup
@@ -132,31 +168,38 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
     __shared__ u32 flagbits[SK_NFLAG];
     __shared__ u32 flagpre[SK_NFLAG + 1];
     __shared__ u32 scan_smem[SK_THREADS / 64 + 1];
+    __shared__ u32 loff[SK_SEQ_CAP + 2];
     __shared__ u8 lut_s[256];
-    __shared__ u32 meta[2];
 
     const u32 tid = threadIdx.x;
     u8 *res_b = (u8 *)res_w;
+#ifdef SK_STAMP
+    unsigned long long sk_t_prev = clock64();
+#endif
 
-    // ---- phase 0: tile -> sequence range (two binary searches), zero LDS state, stage the LUT
-    if (MODE == 1) {
-        if (tid == 0) { u32 s = A.seq_list[blockIdx.x]; meta[0] = s; meta[1] = s + 1; }
-    } else {
-        if (tid == 0) meta[0] = sk_lower_bound(A.offs, 0, A.n_seqs, (u64)blockIdx.x * SK_R);
-        if (tid == 64) meta[1] = sk_lower_bound(A.offs, 0, A.n_seqs, ((u64)blockIdx.x + 1) * SK_R);
-    }
+    // ---- phase 0: tile -> sequence range (planned ahead), zero LDS state, stage LUT + sequence boundaries
+    u32 s_first, s_end;
+    if (MODE == 1) { s_first = A.seq_list[blockIdx.x]; s_end = s_first + 1; }
+    else { s_first = A.seq_list[blockIdx.x]; s_end = A.seq_list[blockIdx.x + 1]; } // seq_list = tile_first here
+    if (s_first >= s_end) return;
+    const u64 r0 = A.offs[s_first];
+    const u64 g0 = r0 & ~15ULL; // A.res is 16-byte aligned (checked on the host)
+    const u32 ns = s_end - s_first;
+    sk_bounds B;
+    B.loff = loff; B.goff = A.offs; B.g0 = g0; B.s_first = s_first; B.in_lds = ns <= SK_SEQ_CAP;
+    if (B.in_lds)
+        for (u32 i = tid; i <= ns; i += SK_THREADS) {
+            u64 v = A.offs[s_first + i] - g0;
+            loff[i] = v > 0x7fffffffULL ? 0x7fffffffu : (u32)v;
+        }
     if (tid < 256) lut_s[tid] = A.lut[tid];
     for (u32 i = tid; i < SK_TILE + 8; i += SK_THREADS) cnt[i] = 0;
     if (tid < SK_NFLAG) flagbits[tid] = 0;
-    __syncthreads();
-    const u32 s_first = meta[0], s_end = meta[1];
-    if (s_first >= s_end) return;
-
-    const u64 r0 = A.offs[s_first];
-    const u64 g0 = r0 & ~15ULL; // A.res is 16-byte aligned (checked on the host)
     u64 span_end = A.offs[s_end];
     if (span_end > g0 + SK_TILE) span_end = g0 + SK_TILE;
+    __syncthreads();
 
+    SK_STAMP_AT(0);
     // ---- phase 1: residues -> LDS through the encode LUT, 16 B per lane
     for (u32 c = tid; c < (SK_TILE + SK_PAD) / 16; c += SK_THREADS) {
         u64 g = g0 + (u64)c * 16;
@@ -180,33 +223,36 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
     }
     __syncthreads();
 
+    SK_STAMP_AT(1);
     // ---- phase 2: hash 8 consecutive windows per thread, bucket + arrival slot via LDS atomics
     const u32 q0 = tid * SK_E;
     sk_seq q;
     {
         // first sequence of the tile whose end lies beyond q0
         u32 lo = s_first, hi = s_end;
-        const u64 x = g0 + q0;
         while (lo < hi) {
             u32 mid = lo + ((hi - lo) >> 1);
-            if (A.offs[mid + 1] > x) hi = mid; else lo = mid + 1;
+            if (B.at(mid + 1) > q0) hi = mid; else lo = mid + 1;
         }
         q.s = lo;
-        sk_load_seq(q, A, g0, s_end);
+        sk_load_seq(q, A, B, s_end);
     }
     const u64 *wl = res_w + tid; // word at byte q0
     u64 h[SK_E];
     u32 bo[SK_E];
-    sk_do_window<0>(A, wl, q0, q, g0, s_end, cnt, h[0], bo[0]);
-    sk_do_window<1>(A, wl, q0, q, g0, s_end, cnt, h[1], bo[1]);
-    sk_do_window<2>(A, wl, q0, q, g0, s_end, cnt, h[2], bo[2]);
-    sk_do_window<3>(A, wl, q0, q, g0, s_end, cnt, h[3], bo[3]);
-    sk_do_window<4>(A, wl, q0, q, g0, s_end, cnt, h[4], bo[4]);
-    sk_do_window<5>(A, wl, q0, q, g0, s_end, cnt, h[5], bo[5]);
-    sk_do_window<6>(A, wl, q0, q, g0, s_end, cnt, h[6], bo[6]);
-    sk_do_window<7>(A, wl, q0, q, g0, s_end, cnt, h[7], bo[7]);
+    h[0] = sk_hash_window<0>(wl, A.k, A.seed);
+    h[1] = sk_hash_window<1>(wl, A.k, A.seed);
+    h[2] = sk_hash_window<2>(wl, A.k, A.seed);
+    h[3] = sk_hash_window<3>(wl, A.k, A.seed);
+    h[4] = sk_hash_window<4>(wl, A.k, A.seed);
+    h[5] = sk_hash_window<5>(wl, A.k, A.seed);
+    h[6] = sk_hash_window<6>(wl, A.k, A.seed);
+    h[7] = sk_hash_window<7>(wl, A.k, A.seed);
+#pragma unroll
+    for (int i = 0; i < SK_E; i++) bo[i] = sk_place_window(A, q0 + i, h[i], q, B, s_end, cnt);
     __syncthreads();
 
+    SK_STAMP_AT(2);
     // ---- phase 3: bucket counts -> bucket starts (exclusive scan over the tile)
     {
         u32 c[SK_E], s = 0;
@@ -222,37 +268,54 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
     }
     __syncthreads();
 
+    SK_STAMP_AT(3);
     // ---- phase 4: scatter kept hashes into bucket order
 #pragma unroll
     for (int i = 0; i < SK_E; i++)
         if (bo[i] != 0xffffffffu) tmp[cnt[bo[i] >> 16] + (bo[i] & 0xffffu)] = h[i];
     __syncthreads();
 
+    SK_STAMP_AT(4);
     // ---- phase 5: rank inside the bucket; first arrival of each distinct hash is its representative
     u32 pr[SK_E]; // (sorted position << 1) | is_representative, or ~0
     u32 ab[SK_E];
+    {
+        u32 sb[SK_E], c[SK_E], less[SK_E], eqb[SK_E];
+        u32 maxc = 0;
 #pragma unroll
-    for (int i = 0; i < SK_E; i++) {
-        pr[i] = 0xffffffffu;
-        ab[i] = 0;
-        if (bo[i] != 0xffffffffu) {
-            const u32 b = bo[i] >> 16, o = bo[i] & 0xffffu;
-            const u32 sb = cnt[b], c = cnt[b + 1] - sb;
-            u32 less = 0, eq = 0, eqb = 0;
-            for (u32 j = 0; j < c; j++) {
-                u64 x = tmp[sb + j];
-                less += x < h[i];
-                eq += x == h[i];
-                eqb += (x == h[i]) & (j < o);
+        for (int i = 0; i < SK_E; i++) {
+            sb[i] = 0; c[i] = 0; less[i] = 0; eqb[i] = 0; ab[i] = 0;
+            if (bo[i] != 0xffffffffu) {
+                const u32 b = bo[i] >> 16;
+                sb[i] = cnt[b];
+                c[i] = cnt[b + 1] - sb[i];
             }
-            const u32 p = sb + less + eqb;
-            pr[i] = (p << 1) | (eqb == 0);
-            ab[i] = eq;
-            if (eqb == 0) atomicOr(&flagbits[p >> 5], 1u << (p & 31));
+            maxc = c[i] > maxc ? c[i] : maxc;
+        }
+        for (u32 j = 0; j < maxc; j++) {
+#pragma unroll
+            for (int i = 0; i < SK_E; i++) {
+                if (j < c[i]) {
+                    const u64 x = tmp[sb[i] + j];
+                    less[i] += x < h[i];
+                    ab[i] += x == h[i];
+                    eqb[i] += (x == h[i]) & (j < (bo[i] & 0xffffu));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SK_E; i++) {
+            pr[i] = 0xffffffffu;
+            if (bo[i] != 0xffffffffu) {
+                const u32 p = sb[i] + less[i] + eqb[i];
+                pr[i] = (p << 1) | (eqb[i] == 0);
+                if (eqb[i] == 0) atomicOr(&flagbits[p >> 5], 1u << (p & 31));
+            }
         }
     }
     __syncthreads();
 
+    SK_STAMP_AT(5);
     // ---- phase 6: prefix over representative flags -> distinct rank
     {
         u32 v = tid < SK_NFLAG ? (u32)__popc(flagbits[tid]) : 0;
@@ -266,10 +329,8 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
 
     // per-sequence unique counts and run starts (tile-packed layout starting at offs[s_first])
     for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
-        u64 b = A.offs[s], e = A.offs[s + 1];
-        u64 len = e - b;
-        if (len > A.len_cap) continue; // a later launch owns it
-        u32 ls = (u32)(b - g0), le = (u32)(e - g0);
+        const u32 ls = B.at(s), le = B.at(s + 1);
+        if (le - ls > A.len_cap) continue; // a later launch owns it
         u32 x0 = cnt[ls], x1 = cnt[le];
         u32 d0 = x0 >= SK_TILE ? n_distinct : flagpre[x0 >> 5] + (u32)__popc(flagbits[x0 >> 5] & ((1u << (x0 & 31)) - 1u));
         u32 d1 = x1 >= SK_TILE ? n_distinct : flagpre[x1 >> 5] + (u32)__popc(flagbits[x1 >> 5] & ((1u << (x1 & 31)) - 1u));
@@ -278,6 +339,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
     }
     __syncthreads();
 
+    SK_STAMP_AT(6);
     // ---- phase 7: representatives -> LDS staging in distinct-rank order (tmp / cnt are free now)
     u32 *abund_s = cnt;
 #pragma unroll
@@ -291,11 +353,13 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
     }
     __syncthreads();
 
+    SK_STAMP_AT(7);
     // ---- phase 8: one contiguous, coalesced run per tile
     for (u32 d = tid; d < n_distinct; d += SK_THREADS) {
         A.sp_hash[r0 + d] = tmp[d];
         A.sp_abund[r0 + d] = abund_s[d];
     }
+    SK_STAMP_AT(8);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -518,7 +582,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     int st = KS_OK;
     u64 *sp_hash = nullptr, *sp_start = nullptr, *d_stats = nullptr;
     u32 *sp_abund = nullptr, *counts = nullptr;
-    u32 *med_ids = nullptr, *long_ids = nullptr, *n_cls = nullptr;
+    u32 *med_ids = nullptr, *long_ids = nullptr, *n_cls = nullptr, *tile_first = nullptr;
     u64 *slab64 = nullptr, *lg_hash = nullptr;
     u32 *slab32 = nullptr, *lg_abund = nullptr;
     u64 n_med = 0, n_long = 0;
@@ -568,9 +632,14 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         }
         A.lut = ctx->d_lut + 256 * p->moltype;
         A.sp_hash = sp_hash; A.sp_abund = sp_abund; A.counts = counts; A.sp_start = sp_start;
-        A.len_cap = SK_LS_MAX; A.seq_list = nullptr; A.start_flag = 0;
+        A.len_cap = SK_LS_MAX; A.start_flag = 0;
         const u64 n_tiles = n_res / SK_R + 1;
-        if (n_tiles > 0x7fffffffULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "batch too large"); goto done; }
+        if (n_tiles > 0x7ffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "batch too large"); goto done; }
+        SK_CHECK(ks_alloc(ctx, &tile_first, (size_t)n_tiles + 1));
+        ks_timer_begin(ctx, "tile_plan");
+        hipLaunchKernelGGL(k_tile_plan, dim3((u32)((n_tiles + 256) / 256)), dim3(256), 0, ctx->stream, d_offs, n_seqs, (u32)n_tiles, tile_first);
+        ks_timer_end(ctx);
+        A.seq_list = tile_first;
         ks_timer_begin(ctx, "sketch_tiles");
         hipLaunchKernelGGL(k_sketch_tiles<0>, dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
         ks_timer_end(ctx);
@@ -638,6 +707,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
 
 done:
     ks_pool_free(ctx, sp_hash); ks_pool_free(ctx, sp_abund); ks_pool_free(ctx, counts); ks_pool_free(ctx, sp_start);
+    ks_pool_free(ctx, tile_first);
     ks_pool_free(ctx, d_stats); ks_pool_free(ctx, med_ids); ks_pool_free(ctx, long_ids); ks_pool_free(ctx, n_cls);
     ks_pool_free(ctx, slab64); ks_pool_free(ctx, slab32); ks_pool_free(ctx, lg_hash); ks_pool_free(ctx, lg_abund);
     if (st != KS_OK) {

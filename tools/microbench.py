@@ -47,7 +47,15 @@ def child(args):
     el = (time.perf_counter() - t0) / args.steps * 1e3
     ctx.timing_enable(False)
     tm = {k_: round(v[1] / args.steps, 3) for k_, v in ctx.timing().items()}
-    print(json.dumps({"variant": args.variant, "ms_per_step": round(el, 3), "stats": r, "kernels": tm}))
+    out = {"variant": args.variant, "ms_per_step": round(el, 3), "stats": r, "kernels": tm}
+    import ctypes
+    L = ks._lib.load()
+    if hasattr(L, "ks_debug_read_stamps"):
+        buf = (ctypes.c_ulonglong * 16)()
+        L.ks_debug_read_stamps(buf, 0)
+        tot = float(sum(buf)) or 1.0
+        out["sketch_phase_share"] = [round(v / tot, 4) for v in buf[:9]]
+    print(json.dumps(out))
 
 
 def main():
