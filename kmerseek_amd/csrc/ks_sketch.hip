@@ -31,6 +31,9 @@
 #define SK_MED_MAX (SK_TILE - 16)   // longest sequence that still fits one tile on its own ("medium")
 #define SK_R (SK_TILE - SK_LS_MAX - 16)
 #define SK_PAD 160                  // >= KS_MAX_KSIZE + 24: slack behind the last residue for word reads
+#ifndef SK_MINW
+#define SK_MINW 6                   // waves per SIMD to compile for: 3 workgroups of 8 waves per CU
+#endif
 #define SK_NFLAG (SK_TILE / 32)
 
 // Diagnostic build only (-DSK_STAMP): per-phase shader-clock shares of k_sketch_tiles, summed over
@@ -62,12 +65,21 @@ struct sk_args {
     const u8 *lut; // 256-byte encode table for this moltype
     u32 len_cap;   // sequences longer than this are not this launch's business
     const u32 *seq_list; // MODE 0: tile_first[n_tiles + 1] (tile -> first sequence); MODE 1: one medium sequence per workgroup
-    u64 start_flag;      // OR-ed into sp_start (marks runs that live in the lg_* buffers)
-    u64 *sp_hash;  // [n_res]   tile-packed unique hashes
-    u32 *sp_abund; // [n_res]
-    u32 *counts;   // [n_seqs]  unique hashes per sequence
-    u64 *sp_start; // [n_seqs]  where the sequence's run starts in sp_hash / sp_abund
+    // MODE 0 writes the final CSR directly: hashes / abunds at csr positions, csr[s] per sequence
+    u64 *out_hash;  // MODE 0: final hashes [n_windows]; MODE 1: lg_hash [n_res] (run of sequence s starts at offs[s])
+    u32 *out_abund;
+    u64 *csr;       // [n_seqs + 1] final CSR offsets (MODE 0)
+    u32 *counts;    // [n_seqs] unique hashes of medium / long sequences (written by MODE 1 / k_sketch_long, read by MODE 0)
+    // decoupled look-back across tiles (MODE 0)
+    unsigned long long *tile_status; // [n_tiles] (flag << 62) | value; flag 1 = tile aggregate, 2 = inclusive prefix
+    u32 *ticket;    // [0] dynamic tile id, [1] error flag (a bounded spin expired)
+    u32 n_tiles;
 };
+
+#define SK_FLAG_AGG (1ULL << 62)
+#define SK_FLAG_PRE (2ULL << 62)
+#define SK_VAL_MASK ((1ULL << 62) - 1)
+#define SK_SPIN_MAX (1u << 22)
 
 // bucket multiplier: bucket = umulhi(h >> 32, mul) < n_windows for every kept h (h <= max_hash)
 KS_DEV u32 sk_bucket_mul(u32 nw, u32 sfix) {
@@ -145,7 +157,8 @@ KS_DEV u32 sk_place_window(const sk_args &A, u32 p, u64 h, sk_seq &q, const sk_b
     u32 bo = 0xffffffffu;
     if (keep) {
         const u32 b = q.ls + __umulhi((u32)(h >> 32), q.mul);
-        const u32 o = atomicAdd(&cnt[b], 1u);
+        const u32 sh = (b & 1u) * 16u;
+        const u32 o = (atomicAdd(&cnt[b >> 1], 1u << sh) >> sh) & 0xffffu; // two 16-bit counters per word
         bo = (b << 16) | o; // b < 4096, o < 4096
     }
     return bo;
@@ -161,9 +174,10 @@ __global__ __launch_bounds__(256) void k_tile_plan(const u64 *offs, u32 n_seqs, 
 
 // MODE 0: shared tiles cut by residue range; MODE 1: one listed medium sequence per workgroup
 template <int MODE>
-__global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
+__global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A) {
     __shared__ __attribute__((aligned(16))) u64 res_w[(SK_TILE + SK_PAD) / 8];
-    __shared__ __attribute__((aligned(16))) u32 cnt[SK_TILE + 8];
+    __shared__ __attribute__((aligned(16))) u32 cnt[SK_TILE / 2 + 4]; // bucket counts, then starts: 16 bits each
+    __shared__ u16 dseq[SK_SEQ_CAP + 2];                               // distinct rank at each sequence start
     __shared__ __attribute__((aligned(16))) u64 tmp[SK_TILE];
     __shared__ u32 flagbits[SK_NFLAG];
     __shared__ u32 flagpre[SK_NFLAG + 1];
@@ -178,10 +192,25 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
 #endif
 
     // ---- phase 0: tile -> sequence range (planned ahead), zero LDS state, stage LUT + sequence boundaries
+    __shared__ u32 tile_s;
+    __shared__ u32 ext_n;
+    __shared__ u32 ext_seq[4], ext_cnt[4], ext_d[4];
+    __shared__ unsigned long long base_s;
+    u32 tile = blockIdx.x;
+    if (MODE == 0) {
+        // tiles are handed out in ticket order, so every predecessor a look-back waits for is already running
+        if (tid == 0) { tile_s = atomicAdd(&A.ticket[0], 1u); ext_n = 0; }
+        __syncthreads();
+        tile = tile_s;
+    }
     u32 s_first, s_end;
-    if (MODE == 1) { s_first = A.seq_list[blockIdx.x]; s_end = s_first + 1; }
-    else { s_first = A.seq_list[blockIdx.x]; s_end = A.seq_list[blockIdx.x + 1]; } // seq_list = tile_first here
-    if (s_first >= s_end) return;
+    if (MODE == 1) { s_first = A.seq_list[tile]; s_end = s_first + 1; }
+    else { s_first = A.seq_list[tile]; s_end = A.seq_list[tile + 1]; }
+    if (s_first >= s_end) {
+        if (MODE == 0 && tid == 0)
+            __hip_atomic_store(&A.tile_status[tile], SK_FLAG_AGG | 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     const u64 r0 = A.offs[s_first];
     const u64 g0 = r0 & ~15ULL; // A.res is 16-byte aligned (checked on the host)
     const u32 ns = s_end - s_first;
@@ -193,7 +222,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
             loff[i] = v > 0x7fffffffULL ? 0x7fffffffu : (u32)v;
         }
     if (tid < 256) lut_s[tid] = A.lut[tid];
-    for (u32 i = tid; i < SK_TILE + 8; i += SK_THREADS) cnt[i] = 0;
+    for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
     if (tid < SK_NFLAG) flagbits[tid] = 0;
     u64 span_end = A.offs[s_end];
     if (span_end > g0 + SK_TILE) span_end = g0 + SK_TILE;
@@ -256,23 +285,26 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
     // ---- phase 3: bucket counts -> bucket starts (exclusive scan over the tile)
     {
         u32 c[SK_E], s = 0;
+        const uint4 w4 = *(const uint4 *)&cnt[q0 >> 1]; // 8 consecutive 16-bit counters
+        const u32 w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-        for (int i = 0; i < SK_E; i++) { c[i] = cnt[q0 + i]; s += c[i]; }
+        for (int i = 0; i < SK_E; i++) { c[i] = (w[i >> 1] >> ((i & 1) * 16)) & 0xffffu; s += c[i]; }
         u32 total;
         u32 ex = ks_block_excl_scan(s, scan_smem, &total);
+        u32 o[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int i = 0; i < SK_E; i++) { cnt[q0 + i] = ex; ex += c[i]; }
-        if (tid == SK_THREADS - 1) {
-            for (int i = 0; i < 8; i++) cnt[SK_TILE + i] = total;
-        }
+        for (int i = 0; i < SK_E; i++) { o[i >> 1] |= ex << ((i & 1) * 16); ex += c[i]; } // starts <= 4096 fit 16 bits
+        *(uint4 *)&cnt[q0 >> 1] = make_uint4(o[0], o[1], o[2], o[3]);
+        if (tid == SK_THREADS - 1) cnt[SK_TILE / 2] = total | (total << 16);
     }
     __syncthreads();
+    auto bstart = [&](u32 b) -> u32 { return (cnt[b >> 1] >> ((b & 1u) * 16u)) & 0xffffu; };
 
     SK_STAMP_AT(3);
     // ---- phase 4: scatter kept hashes into bucket order
 #pragma unroll
     for (int i = 0; i < SK_E; i++)
-        if (bo[i] != 0xffffffffu) tmp[cnt[bo[i] >> 16] + (bo[i] & 0xffffu)] = h[i];
+        if (bo[i] != 0xffffffffu) tmp[bstart(bo[i] >> 16) + (bo[i] & 0xffffu)] = h[i];
     __syncthreads();
 
     SK_STAMP_AT(4);
@@ -287,8 +319,8 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
             sb[i] = 0; c[i] = 0; less[i] = 0; eqb[i] = 0; ab[i] = 0;
             if (bo[i] != 0xffffffffu) {
                 const u32 b = bo[i] >> 16;
-                sb[i] = cnt[b];
-                c[i] = cnt[b + 1] - sb[i];
+                sb[i] = bstart(b);
+                c[i] = bstart(b + 1) - sb[i];
             }
             maxc = c[i] > maxc ? c[i] : maxc;
         }
@@ -327,37 +359,113 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(sk_args A) {
     __syncthreads();
     const u32 n_distinct = flagpre[SK_NFLAG];
 
-    // per-sequence unique counts and run starts (tile-packed layout starting at offs[s_first])
-    for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
-        const u32 ls = B.at(s), le = B.at(s + 1);
-        if (le - ls > A.len_cap) continue; // a later launch owns it
-        u32 x0 = cnt[ls], x1 = cnt[le];
-        u32 d0 = x0 >= SK_TILE ? n_distinct : flagpre[x0 >> 5] + (u32)__popc(flagbits[x0 >> 5] & ((1u << (x0 & 31)) - 1u));
-        u32 d1 = x1 >= SK_TILE ? n_distinct : flagpre[x1 >> 5] + (u32)__popc(flagbits[x1 >> 5] & ((1u << (x1 & 31)) - 1u));
-        A.counts[s] = d1 - d0;
-        A.sp_start[s] = (r0 + d0) | A.start_flag;
-    }
-    __syncthreads();
-
-    SK_STAMP_AT(6);
-    // ---- phase 7: representatives -> LDS staging in distinct-rank order (tmp / cnt are free now)
-    u32 *abund_s = cnt;
+    auto drank = [&](u32 x) -> u32 { // representatives among sorted positions < x
+        return x >= SK_TILE ? n_distinct : flagpre[x >> 5] + (u32)__popc(flagbits[x >> 5] & ((1u << (x & 31)) - 1u));
+    };
+    u16 *abund_s = (u16 *)cnt; // abundance staging reuses the bucket-start words once they are dead (<= 4096 fits 16 bits)
+    auto stage_reps = [&]() { // representatives -> LDS in distinct-rank order (tmp is free after phase 5)
 #pragma unroll
-    for (int i = 0; i < SK_E; i++) {
-        if (pr[i] != 0xffffffffu && (pr[i] & 1u)) {
-            const u32 p = pr[i] >> 1;
-            const u32 d = flagpre[p >> 5] + (u32)__popc(flagbits[p >> 5] & ((1u << (p & 31)) - 1u));
-            tmp[d] = h[i];
-            abund_s[d] = ab[i];
+        for (int i = 0; i < SK_E; i++) {
+            if (pr[i] != 0xffffffffu && (pr[i] & 1u)) {
+                const u32 d = drank(pr[i] >> 1);
+                tmp[d] = h[i];
+                abund_s[d] = (u16)ab[i];
+            }
         }
-    }
-    __syncthreads();
+    };
 
-    SK_STAMP_AT(7);
-    // ---- phase 8: one contiguous, coalesced run per tile
-    for (u32 d = tid; d < n_distinct; d += SK_THREADS) {
-        A.sp_hash[r0 + d] = tmp[d];
-        A.sp_abund[r0 + d] = abund_s[d];
+    if (MODE == 1) {
+        if (tid == 0) A.counts[s_first] = n_distinct;
+        __syncthreads();
+        SK_STAMP_AT(6);
+        stage_reps();
+        __syncthreads();
+        SK_STAMP_AT(7);
+        // into the side buffer at the sequence's own offset; k_place_long moves it once its CSR slot is known
+        for (u32 d = tid; d < n_distinct; d += SK_THREADS) {
+            A.out_hash[r0 + d] = tmp[d];
+            A.out_abund[r0 + d] = abund_s[d];
+        }
+    } else {
+        // distinct rank at every sequence start; medium / long sequences that start inside this tile (at most
+        // 2-3) bring their unique counts from the earlier launches into the aggregate and the positions behind them
+        for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
+            const u32 ls = B.at(s), le = B.at(s + 1);
+            const u32 d0 = drank(bstart(ls));
+            if (B.in_lds) dseq[s - s_first] = (u16)d0;
+            if (le - ls > A.len_cap) {
+                const u32 e = atomicAdd(&ext_n, 1u);
+                if (e < 4) { ext_seq[e] = s; ext_cnt[e] = A.counts[s]; ext_d[e] = d0; }
+            }
+        }
+        __syncthreads();
+        const u32 ne = ext_n < 4 ? ext_n : 4;
+        u64 agg = n_distinct;
+        for (u32 e = 0; e < ne; e++) agg += ext_cnt[e];
+        // ---- decoupled look-back, step 1: publish this tile's aggregate as early as possible
+        if (tid == 0)
+            __hip_atomic_store(&A.tile_status[tile], (tile == 0 ? SK_FLAG_PRE : SK_FLAG_AGG) | agg, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        if (B.in_lds) { // bucket starts are dead (dseq holds what the CSR needs): stage now, look back after
+            stage_reps();
+            __syncthreads();
+        }
+        SK_STAMP_AT(6);
+        // ---- step 2: wave 0 sums the predecessors' aggregates back to the nearest inclusive prefix
+        if (tid < 64) {
+            u64 excl = 0;
+            if (tile > 0) {
+                i64 idx = (i64)tile - 1;
+                bool done = false;
+                u32 spins = 0;
+                while (!done) {
+                    const i64 mine = idx - (i64)tid;
+                    u64 v = SK_FLAG_PRE; // before tile 0: inclusive prefix 0
+                    if (mine >= 0) {
+                        v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        while ((v >> 62) == 0 && spins < SK_SPIN_MAX) {
+                            __builtin_amdgcn_s_sleep(1);
+                            v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            spins++;
+                        }
+                    }
+                    if ((v >> 62) == 0) { A.ticket[1] = 1; v = SK_FLAG_PRE; } // spin bound expired: flag the error, do not hang
+                    const u64 is_pre = __ballot((v >> 62) == 2);
+                    // lanes at or before the first inclusive prefix contribute
+                    const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
+                    u64 contrib = tid <= first ? (v & SK_VAL_MASK) : 0;
+                    for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+                    excl += contrib;
+                    if (is_pre) done = true; else idx -= 64;
+                }
+                if (tid == 0)
+                    __hip_atomic_store(&A.tile_status[tile], SK_FLAG_PRE | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 0) base_s = excl;
+        }
+        __syncthreads();
+        const u64 base = base_s;
+        // final CSR offsets of every sequence that starts in this tile
+        for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
+            u64 pos = base + (B.in_lds ? (u32)dseq[s - s_first] : drank(bstart(B.at(s))));
+            for (u32 e = 0; e < ne; e++) pos += ext_seq[e] < s ? ext_cnt[e] : 0;
+            A.csr[s] = pos;
+        }
+        if (s_end == A.n_seqs && tid == 0) A.csr[A.n_seqs] = base + agg;
+        if (!B.in_lds) { // rare: more sequences than the LDS table holds, so the starts were needed until here
+            __syncthreads();
+            stage_reps();
+            __syncthreads();
+        }
+        SK_STAMP_AT(7);
+        // ---- phase 8: coalesced write-out straight into the final CSR arrays (runs of medium / long neighbours
+        // leave gaps that k_place_long fills)
+        for (u32 d = tid; d < n_distinct; d += SK_THREADS) {
+            u64 pos = base + d;
+            for (u32 e = 0; e < ne; e++) pos += ext_d[e] <= d ? ext_cnt[e] : 0;
+            A.out_hash[pos] = tmp[d];
+            A.out_abund[pos] = abund_s[d];
+        }
     }
     SK_STAMP_AT(8);
 }
@@ -380,7 +488,6 @@ struct sk_long_args {
     u64 *lg_hash;   // [n_res] output of long sequences (own buffer: a tile-packed run may overlap a long span)
     u32 *lg_abund;  // [n_res]
 };
-#define SK_LONG_FLAG (1ULL << 63)
 
 // n_cls[0] = medium sequences (own tile), n_cls[1] = long sequences (global-slab path)
 __global__ __launch_bounds__(256) void k_find_long(const u64 *offs, u32 n_seqs, u32 *med_ids, u32 *long_ids, u32 *n_cls) {
@@ -512,30 +619,22 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
                 L.lg_abund[b + flag[p]] = abd[p];
             }
         }
-        if (tid == 0) { A.counts[s] = n_distinct; A.sp_start[s] = b | SK_LONG_FLAG; }
+        if (tid == 0) A.counts[s] = n_distinct;
         SK_LONG_SYNC();
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// CSR assembly
+// CSR assembly: only medium / long sequences need a copy (their runs were produced in side buffers
+// before the tile kernel fixed their CSR positions); one workgroup per such sequence.
 // ---------------------------------------------------------------------------------------------
-// one wave per sequence: gather its run from the tile-packed buffers into the final CSR
-__global__ __launch_bounds__(256) void k_sketch_gather(const u64 *sp_hash, const u32 *sp_abund, const u64 *lg_hash,
-                                                       const u32 *lg_abund, const u64 *sp_start, const u64 *csr,
-                                                       u32 n_seqs, u64 *hashes, u32 *abunds) {
-    const u32 s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= n_seqs) return;
-    const u32 lane = threadIdx.x & 63;
-    const u64 dst = csr[s], n = csr[s + 1] - dst;
-    if (n == 0) return;
-    u64 src = sp_start[s];
-    const u64 *sh = sp_hash;
-    const u32 *sa = sp_abund;
-    if (src & SK_LONG_FLAG) { src &= ~SK_LONG_FLAG; sh = lg_hash; sa = lg_abund; }
-    for (u64 i = lane; i < n; i += 64) {
-        hashes[dst + i] = sh[src + i];
-        abunds[dst + i] = sa[src + i];
+__global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u64 *offs, const u64 *csr, const u64 *lg_hash,
+                                                    const u32 *lg_abund, u64 *hashes, u32 *abunds) {
+    const u32 s = ids[blockIdx.x];
+    const u64 dst = csr[s], n = csr[s + 1] - dst, src = offs[s];
+    for (u64 i = threadIdx.x; i < n; i += 256) {
+        hashes[dst + i] = lg_hash[src + i];
+        abunds[dst + i] = lg_abund[src + i];
     }
 }
 
@@ -580,9 +679,10 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     *out = nullptr;
 
     int st = KS_OK;
-    u64 *sp_hash = nullptr, *sp_start = nullptr, *d_stats = nullptr;
-    u32 *sp_abund = nullptr, *counts = nullptr;
-    u32 *med_ids = nullptr, *long_ids = nullptr, *n_cls = nullptr, *tile_first = nullptr;
+    u64 *d_stats = nullptr;
+    u32 *counts = nullptr;
+    u32 *med_ids = nullptr, *long_ids = nullptr, *n_cls = nullptr, *tile_first = nullptr, *ticket = nullptr;
+    unsigned long long *tile_status = nullptr;
     u64 *slab64 = nullptr, *lg_hash = nullptr;
     u32 *slab32 = nullptr, *lg_abund = nullptr;
     u64 n_med = 0, n_long = 0;
@@ -616,14 +716,15 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         n_med = ctx->h_pin[2];
         n_long = ctx->h_pin[3];
     }
-
-    SK_CHECK(ks_alloc(ctx, &sp_hash, (size_t)n_res + 1));
-    SK_CHECK(ks_alloc(ctx, &sp_abund, (size_t)n_res + 1));
-    SK_CHECK(ks_alloc(ctx, &counts, (size_t)n_seqs));
-    SK_CHECK(ks_alloc(ctx, &sp_start, (size_t)n_seqs));
-    SK_HIPCHECK(hipMemsetAsync(counts, 0, (size_t)n_seqs * sizeof(u32), ctx->stream));
     {
+        // final arrays sized by the window count (an upper bound on the kept hashes); the tile kernel writes
+        // them in place, so there is no compaction pass
+        SK_CHECK(ks_alloc(ctx, &S->d_hashes, (size_t)S->n_windows));
+        SK_CHECK(ks_alloc(ctx, &S->d_abunds, (size_t)S->n_windows));
+        SK_CHECK(ks_alloc(ctx, &counts, (size_t)n_seqs));
+
         sk_args A;
+        memset(&A, 0, sizeof A);
         A.res = d_res; A.offs = d_offs; A.n_seqs = n_seqs; A.n_res = n_res; A.k = p->ksize; A.seed = p->seed;
         A.max_hash = ks_max_hash(p->scaled);
         {
@@ -631,23 +732,10 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             A.sfix = sf > 0x7fffffffULL ? 0x7fffffffu : (u32)sf; // smaller only coarsens the buckets
         }
         A.lut = ctx->d_lut + 256 * p->moltype;
-        A.sp_hash = sp_hash; A.sp_abund = sp_abund; A.counts = counts; A.sp_start = sp_start;
-        A.len_cap = SK_LS_MAX; A.start_flag = 0;
-        const u64 n_tiles = n_res / SK_R + 1;
-        if (n_tiles > 0x7ffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "batch too large"); goto done; }
-        SK_CHECK(ks_alloc(ctx, &tile_first, (size_t)n_tiles + 1));
-        ks_timer_begin(ctx, "tile_plan");
-        hipLaunchKernelGGL(k_tile_plan, dim3((u32)((n_tiles + 256) / 256)), dim3(256), 0, ctx->stream, d_offs, n_seqs, (u32)n_tiles, tile_first);
-        ks_timer_end(ctx);
-        A.seq_list = tile_first;
-        ks_timer_begin(ctx, "sketch_tiles");
-        hipLaunchKernelGGL(k_sketch_tiles<0>, dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
-        ks_timer_end(ctx);
-        SK_HIPCHECK(hipGetLastError());
+        A.counts = counts;
 
+        // ---- medium / long sequences first: their unique counts feed the tile kernel's CSR prefix
         if (n_med + n_long > 0) {
-            // runs of medium / long sequences live in their own buffers: a shared tile's packed run may
-            // extend over the residue span of a long neighbour
             SK_CHECK(ks_alloc(ctx, &lg_hash, (size_t)n_res + 1));
             SK_CHECK(ks_alloc(ctx, &lg_abund, (size_t)n_res + 1));
             SK_CHECK(ks_alloc(ctx, &med_ids, (size_t)n_med + 1));
@@ -661,8 +749,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         }
         if (n_med > 0) {
             sk_args M = A;
-            M.sp_hash = lg_hash; M.sp_abund = lg_abund; M.len_cap = SK_MED_MAX; M.seq_list = med_ids;
-            M.start_flag = SK_LONG_FLAG;
+            M.out_hash = lg_hash; M.out_abund = lg_abund; M.len_cap = SK_MED_MAX; M.seq_list = med_ids;
             ks_timer_begin(ctx, "sketch_medium");
             hipLaunchKernelGGL(k_sketch_tiles<1>, dim3((u32)n_med), dim3(SK_THREADS), 0, ctx->stream, M);
             ks_timer_end(ctx);
@@ -689,25 +776,50 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
         }
+
+        // ---- shared tiles: hash + sort/unique + CSR placement in one kernel (decoupled look-back across tiles)
+        const u64 n_tiles = n_res / SK_R + 1;
+        if (n_tiles > 0x7ffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "batch too large"); goto done; }
+        SK_CHECK(ks_alloc(ctx, &tile_first, (size_t)n_tiles + 1));
+        SK_CHECK(ks_alloc(ctx, &tile_status, (size_t)n_tiles));
+        SK_CHECK(ks_alloc(ctx, &ticket, 2));
+        SK_HIPCHECK(hipMemsetAsync(tile_status, 0, (size_t)n_tiles * sizeof(unsigned long long), ctx->stream));
+        SK_HIPCHECK(hipMemsetAsync(ticket, 0, 2 * sizeof(u32), ctx->stream));
+        ks_timer_begin(ctx, "tile_plan");
+        hipLaunchKernelGGL(k_tile_plan, dim3((u32)((n_tiles + 256) / 256)), dim3(256), 0, ctx->stream, d_offs, n_seqs, (u32)n_tiles, tile_first);
+        ks_timer_end(ctx);
+        A.seq_list = tile_first; A.len_cap = SK_LS_MAX;
+        A.out_hash = S->d_hashes; A.out_abund = S->d_abunds; A.csr = S->d_offsets;
+        A.tile_status = tile_status; A.ticket = ticket; A.n_tiles = (u32)n_tiles;
+        ks_timer_begin(ctx, "sketch_tiles");
+        hipLaunchKernelGGL(k_sketch_tiles<0>, dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
+        ks_timer_end(ctx);
+        SK_HIPCHECK(hipGetLastError());
+
+        // ---- runs of medium / long sequences into their CSR slots
+        if (n_med > 0) {
+            ks_timer_begin(ctx, "place_long");
+            hipLaunchKernelGGL(k_place_long, dim3((u32)n_med), dim3(256), 0, ctx->stream, (const u32 *)med_ids, d_offs,
+                               (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds);
+            ks_timer_end(ctx);
+        }
+        if (n_long > 0) {
+            ks_timer_begin(ctx, "place_long");
+            hipLaunchKernelGGL(k_place_long, dim3((u32)n_long), dim3(256), 0, ctx->stream, (const u32 *)long_ids, d_offs,
+                               (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds);
+            ks_timer_end(ctx);
+        }
+        SK_HIPCHECK(hipGetLastError());
+        // total + look-back error flag to the host
+        SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, S->d_offsets + n_seqs, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin + 1, ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
+        S->n_hashes = ctx->h_pin[0];
+        if (((u32 *)(ctx->h_pin + 1))[1] != 0) { st = ks_fail(ctx, KS_ERR_HIP, "sketch: tile look-back timed out"); goto done; }
     }
-    // counts -> CSR offsets; total to the host to size the final arrays
-    SK_CHECK(ks_scan_u32_to_u64(ctx, counts, S->d_offsets, n_seqs));
-    SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, S->d_offsets + n_seqs, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-    SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
-    S->n_hashes = ctx->h_pin[0];
-    SK_CHECK(ks_alloc(ctx, &S->d_hashes, (size_t)S->n_hashes));
-    SK_CHECK(ks_alloc(ctx, &S->d_abunds, (size_t)S->n_hashes));
-    ks_timer_begin(ctx, "sketch_gather");
-    hipLaunchKernelGGL(k_sketch_gather, dim3((n_seqs + 3) / 4), dim3(256), 0, ctx->stream, (const u64 *)sp_hash,
-                       (const u32 *)sp_abund, (const u64 *)lg_hash, (const u32 *)lg_abund, (const u64 *)sp_start,
-                       (const u64 *)S->d_offsets, n_seqs, S->d_hashes, S->d_abunds);
-    ks_timer_end(ctx);
-    SK_HIPCHECK(hipGetLastError());
-    SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
 
 done:
-    ks_pool_free(ctx, sp_hash); ks_pool_free(ctx, sp_abund); ks_pool_free(ctx, counts); ks_pool_free(ctx, sp_start);
-    ks_pool_free(ctx, tile_first);
+    ks_pool_free(ctx, counts); ks_pool_free(ctx, tile_first); ks_pool_free(ctx, tile_status); ks_pool_free(ctx, ticket);
     ks_pool_free(ctx, d_stats); ks_pool_free(ctx, med_ids); ks_pool_free(ctx, long_ids); ks_pool_free(ctx, n_cls);
     ks_pool_free(ctx, slab64); ks_pool_free(ctx, slab32); ks_pool_free(ctx, lg_hash); ks_pool_free(ctx, lg_abund);
     if (st != KS_OK) {
