@@ -143,6 +143,10 @@ int ks_sketches_copy_to_host(ks_ctx *ctx, const ks_sketches *s, uint64_t *offset
 int ks_sketches_from_host(ks_ctx *ctx, const uint64_t *offsets, const uint64_t *hashes,
                           const uint32_t *abunds, uint32_t n_seqs, const ks_params *params,
                           ks_sketches **out);
+/* Union of all sequences' sketches with abundances summed per hash, returned as ONE sequence: the
+ * "combined minhash" that ProteomeIndex::store_signatures maintains (src/rust/index.rs:800-830,
+ * add_many_with_abund under a mutex there).  Abundance sums saturate at 2^32-1. */
+int ks_sketches_union(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out);
 void ks_sketches_free(ks_sketches *s);
 
 /* ---- k-mer positions ----------------------------------------------------------------------- */

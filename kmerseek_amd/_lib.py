@@ -71,6 +71,7 @@ SIGNATURES = {
     "ks_sketches_device_abunds": (_vp, [_vp]),
     "ks_sketches_copy_to_host": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ks_sketches_from_host": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _parp, _pp]),
+    "ks_sketches_union": (C.c_int, [_vp, _vp, _pp]),
     "ks_sketches_free": (None, [_vp]),
     "ks_kmer_positions": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _parp, _pp]),
     "ks_kmerpos_count": (C.c_uint64, [_vp]),

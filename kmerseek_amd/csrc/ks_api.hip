@@ -102,6 +102,11 @@ extern "C" int ks_sketches_from_host(ks_ctx *ctx, const uint64_t *offsets, const
     return KS_OK;
 }
 
+extern "C" int ks_sketches_union(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    return ks_union_impl(ctx, in, out);
+}
+
 extern "C" void ks_sketches_free(ks_sketches *s) {
     if (!s) return;
     ks_pool_free(s->ctx, s->d_offsets);

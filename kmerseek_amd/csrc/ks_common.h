@@ -154,5 +154,6 @@ int ks_kmerpos_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 
                            const ks_params *p, ks_kmerpos **out);
 int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out);
 int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out);
+int ks_union_impl(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out);
 
 int ks_check_params(ks_ctx *ctx, const ks_params *p);

@@ -1,0 +1,640 @@
+// ks_host.cpp — C++ host mirror of the reference's ProteomeIndex (include/kmerseek_host.hpp) and its flat C
+// shim (include/kmerseek_host_c.h).  Pure host code above the compute ABI: all hashing / sorting happens in
+// the HIP library through ks_sketch_batch / ks_kmer_positions / ks_sketches_union.
+#include "../../include/kmerseek_host.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <thread>
+
+#include "../../include/kmerseek_amd.h"
+#include "../../include/kmerseek_host_c.h"
+
+namespace kmerseek {
+
+size_t KmerInfo::total_occurrences() const {
+    size_t n = 0;
+    for (auto &kv : original_kmer_to_position) n += kv.second.size();
+    return n;
+}
+
+static IndexError gpu_error(ks_ctx *ctx, int st, const char *what) {
+    std::string msg = std::string(what) + ": " + (ctx ? ks_last_error(ctx) : ks_status_string(st));
+    if (st == KS_ERR_INVALID_MOLTYPE) return IndexError(IndexError::SourmashError, "Sourmash error: " + std::string(ctx ? ks_last_error(ctx) : ""));
+    return IndexError(IndexError::Gpu, msg);
+}
+
+static std::string hex64(uint64_t v) { // format!("{:x}", v), signature.rs:279
+    char b[32];
+    snprintf(b, sizeof b, "%llx", (unsigned long long)v);
+    return b;
+}
+
+// sourmash aa_to_dayhoff / aa_to_hp (selected at encoding.rs:43-53) — only used to spell `encoded_kmer` strings
+static char encode_residue(char c, uint32_t moltype) {
+    if (moltype == KS_PROTEIN) return c;
+    if (moltype == KS_DAYHOFF) {
+        switch (c) {
+        case 'C': return 'a';
+        case 'A': case 'G': case 'P': case 'S': case 'T': return 'b';
+        case 'D': case 'E': case 'N': case 'Q': return 'c';
+        case 'H': case 'K': case 'R': return 'd';
+        case 'I': case 'L': case 'M': case 'V': return 'e';
+        case 'F': case 'W': case 'Y': return 'f';
+        default: return 'X';
+        }
+    }
+    switch (c) {
+    case 'A': case 'F': case 'G': case 'I': case 'L': case 'M': case 'P': case 'V': case 'W': case 'Y': return 'h';
+    case 'N': case 'C': case 'S': case 'T': case 'D': case 'E': case 'R': case 'H': case 'K': case 'Q': return 'p';
+    default: return 'X';
+    }
+}
+
+ProteomeIndex::ProteomeIndex(const std::string &path, uint32_t ksize, uint32_t scaled, const std::string &moltype,
+                             bool store_raw_sequences, int device)
+    : path_(path), ksize_(ksize), scaled_(scaled), moltype_(moltype), store_raw_(store_raw_sequences) {
+    // get_hash_function_from_moltype failure is wrapped as IndexError::SourmashError (index.rs:168-172)
+    if (ks_moltype_from_string(moltype.c_str(), &moltype_id_) != KS_OK)
+        throw IndexError(IndexError::SourmashError, "Sourmash error: Invalid moltype: " + moltype +
+                                                        ", only 'protein', 'hp', or 'dayhoff' are supported");
+    if (ksize < 1 || ksize > KS_MAX_KSIZE)
+        throw IndexError(IndexError::InvalidKsize, "Invalid k-mer size: " + std::to_string(ksize));
+    if (scaled < 1) throw IndexError(IndexError::ValidationError, "Validation error: scaled must be >= 1");
+    int st = ks_ctx_create(device, nullptr, &ctx_);
+    if (st != KS_OK) throw IndexError(IndexError::Gpu, std::string("ks_ctx_create failed: ") + ks_status_string(st) + " (no CPU fallback)");
+}
+
+ProteomeIndex::~ProteomeIndex() {
+    if (ctx_) ks_ctx_destroy(ctx_);
+}
+
+ProteomeIndexBuilder ProteomeIndex::builder() { return ProteomeIndexBuilder(); }
+
+static void split_path(const std::string &p, std::string &parent, std::string &file) {
+    size_t pos = p.find_last_of('/');
+    if (pos == std::string::npos) { parent = ""; file = p; }
+    else { parent = p.substr(0, pos); file = p.substr(pos + 1); }
+}
+
+std::unique_ptr<ProteomeIndex> ProteomeIndex::new_with_auto_filename(const std::string &base_path, uint32_t ksize,
+                                                                      uint32_t scaled, const std::string &moltype,
+                                                                      bool store_raw_sequences, int device) {
+    std::string parent, file;
+    split_path(base_path, parent, file);
+    std::string name = file + "." + moltype + ".k" + std::to_string(ksize) + ".scaled" + std::to_string(scaled) + ".kmerseek.rocksdb";
+    std::string full = parent.empty() ? name : parent + "/" + name;
+    return std::make_unique<ProteomeIndex>(full, ksize, scaled, moltype, store_raw_sequences, device);
+}
+
+std::string ProteomeIndex::generate_filename(const std::string &base_name) const {
+    return base_name + "." + moltype_ + ".k" + std::to_string(ksize_) + ".scaled" + std::to_string(scaled_) + ".kmerseek.rocksdb";
+}
+
+ProteinSignature ProteomeIndex::create_protein_signature(const std::string &sequence, const std::string &name) {
+    // called directly, the sequence is NOT upper-cased (only the FASTA path is: index.rs:1000)
+    auto v = create_protein_signatures({{sequence, name}}, false);
+    return std::move(v[0]);
+}
+
+std::vector<ProteinSignature> ProteomeIndex::create_protein_signatures(
+    const std::vector<std::pair<std::string, std::string>> &records, bool upper) {
+    const size_t n = records.size();
+    std::vector<ProteinSignature> out(n);
+    if (n == 0) return out;
+    // ---- host pre-step, parallel over records: validate / resolve (aminoacid.rs:74-105)
+    std::vector<std::string> processed(n);
+    std::vector<ks_residue_error> errs(n);
+    std::vector<int> status(n, KS_OK);
+    unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16));
+    if (n < 64) nt = 1;
+    auto work = [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const std::string &s = records[i].first;
+            processed[i].resize(s.size());
+            uint64_t olen = 0;
+            status[i] = ks_validate_and_resolve((const uint8_t *)s.data(), s.size(), upper ? 1 : 0,
+                                                rng_seed_ + 0x9e3779b97f4a7c15ULL * (i + 1), (uint8_t *)&processed[i][0], &olen, &errs[i]);
+            processed[i].resize(olen);
+        }
+    };
+    if (nt == 1) work(0, n);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        for (auto &t : th) t.join();
+    }
+    rng_seed_ += n;
+    for (size_t i = 0; i < n; i++)
+        if (status[i] != KS_OK) { // first failing record aborts the batch (index.rs:993-1008)
+            char msg[128];
+            snprintf(msg, sizeof msg, "Invalid amino acid '%c' found at position %u", (char)errs[i].residue, errs[i].position);
+            IndexError e(IndexError::InvalidAminoAcid, msg);
+            e.residue = (char)errs[i].residue; e.position = errs[i].position; e.seq_index = i;
+            throw e;
+        }
+    // ---- pack and run the two batched GPU calls
+    std::vector<uint64_t> offs(n + 1, 0);
+    for (size_t i = 0; i < n; i++) offs[i + 1] = offs[i] + processed[i].size();
+    std::vector<uint8_t> res(offs[n] + 1);
+    for (size_t i = 0; i < n; i++) memcpy(res.data() + offs[i], processed[i].data(), processed[i].size());
+    ks_params p{ksize_, scaled_, moltype_id_, 0, SEED};
+    ks_sketches *S = nullptr;
+    int st = ks_sketch_batch(ctx_, res.data(), offs.data(), (uint32_t)n, &p, &S);
+    if (st != KS_OK) throw gpu_error(ctx_, st, "ks_sketch_batch");
+    std::vector<uint64_t> so(n + 1), sh(ks_sketches_n_hashes(S) + 1);
+    std::vector<uint32_t> sa(sh.size());
+    st = ks_sketches_copy_to_host(ctx_, S, so.data(), sh.data(), sa.data());
+    ks_sketches_free(S);
+    if (st != KS_OK) throw gpu_error(ctx_, st, "ks_sketches_copy_to_host");
+    ks_kmerpos *K = nullptr;
+    st = ks_kmer_positions(ctx_, res.data(), offs.data(), (uint32_t)n, &p, &K);
+    if (st != KS_OK) throw gpu_error(ctx_, st, "ks_kmer_positions");
+    const uint64_t np = ks_kmerpos_count(K);
+    std::vector<uint32_t> pseq(np + 1), pstart(np + 1);
+    std::vector<uint64_t> phash(np + 1);
+    st = ks_kmerpos_copy_to_host(ctx_, K, pseq.data(), pstart.data(), phash.data());
+    ks_kmerpos_free(K);
+    if (st != KS_OK) throw gpu_error(ctx_, st, "ks_kmerpos_copy_to_host");
+    // ---- build the signatures
+    for (size_t i = 0; i < n; i++) {
+        ProteinSignature &g = out[i];
+        g.name = records[i].second;
+        g.moltype = moltype_;
+        g.protein_ksize = ksize_;
+        g.scaled = scaled_;
+        g.mins.assign(sh.begin() + so[i], sh.begin() + so[i + 1]);
+        g.abunds.assign(sa.begin() + so[i], sa.begin() + so[i + 1]);
+        uint64_t sum = 0;
+        for (uint64_t m : g.mins) sum += m; // wrapping
+        g.md5sum = hex64(sum);
+        if (store_raw_) g.raw_sequence = processed[i];
+    }
+    for (uint64_t j = 0; j < np; j++) { // triples are ordered by (seq, start): positions come out ascending
+        ProteinSignature &g = out[pseq[j]];
+        const std::string &seq = processed[pseq[j]];
+        KmerInfo &ki = g.kmer_infos[phash[j]];
+        if (ki.encoded_kmer.empty()) {
+            ki.ksize = ksize_;
+            ki.hashval = phash[j];
+            ki.encoded_kmer.resize(ksize_);
+            for (uint32_t c = 0; c < ksize_; c++) ki.encoded_kmer[c] = encode_residue(seq[pstart[j] + c], moltype_id_);
+        }
+        ki.original_kmer_to_position[seq.substr(pstart[j], ksize_)].push_back(pstart[j]);
+    }
+    return out;
+}
+
+void ProteomeIndex::process_kmers(const std::string &sequence, ProteinSignature &sig) {
+    std::vector<uint64_t> offs{0, sequence.size()};
+    ks_params p{ksize_, scaled_, moltype_id_, 0, SEED};
+    ks_kmerpos *K = nullptr;
+    int st = ks_kmer_positions(ctx_, (const uint8_t *)sequence.data(), offs.data(), 1, &p, &K);
+    if (st != KS_OK) throw gpu_error(ctx_, st, "ks_kmer_positions");
+    const uint64_t np = ks_kmerpos_count(K);
+    std::vector<uint32_t> pseq(np + 1), pstart(np + 1);
+    std::vector<uint64_t> phash(np + 1);
+    st = ks_kmerpos_copy_to_host(ctx_, K, pseq.data(), pstart.data(), phash.data());
+    ks_kmerpos_free(K);
+    if (st != KS_OK) throw gpu_error(ctx_, st, "ks_kmerpos_copy_to_host");
+    for (uint64_t j = 0; j < np; j++) {
+        // "if this hashval is in the minhash" (index.rs:769): FracMinHash membership == kept by the threshold,
+        // checked against the signature anyway so a foreign signature behaves like the reference
+        if (!std::binary_search(sig.mins.begin(), sig.mins.end(), phash[j])) continue;
+        KmerInfo &ki = sig.kmer_infos[phash[j]];
+        if (ki.encoded_kmer.empty()) {
+            ki.ksize = ksize_;
+            ki.hashval = phash[j];
+            ki.encoded_kmer.resize(ksize_);
+            for (uint32_t c = 0; c < ksize_; c++) ki.encoded_kmer[c] = encode_residue(sequence[pstart[j] + c], moltype_id_);
+        }
+        ki.original_kmer_to_position[sequence.substr(pstart[j], ksize_)].push_back(pstart[j]);
+    }
+}
+
+void ProteomeIndex::store_signatures(std::vector<ProteinSignature> sigs) {
+    // combined sketch: union with summed abundances (index.rs:803-827), done on the GPU for the batch and
+    // merged into the running (sorted) combined sketch on the host
+    std::vector<uint64_t> offs(sigs.size() + 1, 0);
+    for (size_t i = 0; i < sigs.size(); i++) offs[i + 1] = offs[i] + sigs[i].mins.size();
+    if (offs.back() > 0) {
+        std::vector<uint64_t> h(offs.back());
+        std::vector<uint32_t> a(offs.back());
+        for (size_t i = 0; i < sigs.size(); i++)
+            for (size_t j = 0; j < sigs[i].mins.size(); j++) {
+                h[offs[i] + j] = sigs[i].mins[j];
+                a[offs[i] + j] = (uint32_t)std::min<uint64_t>(sigs[i].abunds[j], 0xffffffffu);
+            }
+        ks_params p{ksize_, scaled_, moltype_id_, 0, SEED};
+        ks_sketches *S = nullptr, *U = nullptr;
+        int st = ks_sketches_from_host(ctx_, offs.data(), h.data(), a.data(), (uint32_t)sigs.size(), &p, &S);
+        if (st != KS_OK) throw gpu_error(ctx_, st, "ks_sketches_from_host");
+        st = ks_sketches_union(ctx_, S, &U);
+        ks_sketches_free(S);
+        if (st != KS_OK) throw gpu_error(ctx_, st, "ks_sketches_union");
+        const uint64_t nu = ks_sketches_n_hashes(U);
+        std::vector<uint64_t> uo(2), uh(nu + 1);
+        std::vector<uint32_t> ua(nu + 1);
+        st = ks_sketches_copy_to_host(ctx_, U, uo.data(), uh.data(), ua.data());
+        ks_sketches_free(U);
+        if (st != KS_OK) throw gpu_error(ctx_, st, "ks_sketches_copy_to_host");
+        std::vector<uint64_t> mm, ma;
+        mm.reserve(combined_mins_.size() + nu);
+        ma.reserve(combined_mins_.size() + nu);
+        size_t i = 0, j = 0;
+        while (i < combined_mins_.size() || j < nu) {
+            if (j >= nu || (i < combined_mins_.size() && combined_mins_[i] < uh[j])) { mm.push_back(combined_mins_[i]); ma.push_back(combined_abunds_[i]); i++; }
+            else if (i >= combined_mins_.size() || uh[j] < combined_mins_[i]) { mm.push_back(uh[j]); ma.push_back(ua[j]); j++; }
+            else { mm.push_back(uh[j]); ma.push_back(combined_abunds_[i] + ua[j]); i++; j++; }
+        }
+        combined_mins_.swap(mm);
+        combined_abunds_.swap(ma);
+    }
+    for (auto &g : sigs) { // same pseudo-md5 overwrites (DashMap::insert, index.rs:817-820)
+        std::string key = g.md5sum;
+        signatures_[key] = std::move(g);
+    }
+}
+
+void ProteomeIndex::store_signatures_batch(const std::vector<ProteinSignature> &sigs) {
+    store_signatures(std::vector<ProteinSignature>(sigs));
+}
+
+void ProteomeIndex::process_fasta(const std::string &fasta_path, uint32_t progress_interval, size_t batch_size) {
+    if (progress_interval > 0) printf("Reading FASTA file with automatic compression detection and parallel processing...\n");
+    {   // zlib reads plain and gzip transparently; other magic numbers are what niffler would have handled
+        FILE *f = fopen(fasta_path.c_str(), "rb");
+        if (!f) throw IndexError(IndexError::ParseError, "Parse error: cannot open " + fasta_path + ": " + strerror(errno));
+        unsigned char m[6] = {0};
+        size_t got = fread(m, 1, 6, f);
+        fclose(f);
+        if (got >= 4 && ((m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd) || (m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') ||
+                         (m[0] == 0xfd && m[1] == '7' && m[2] == 'z' && m[3] == 'X')))
+            throw IndexError(IndexError::ParseError, "Parse error: zstd / bzip2 / xz input is not supported by this build (plain or gzip only): " + fasta_path);
+    }
+    gzFile gz = gzopen(fasta_path.c_str(), "rb");
+    if (!gz) throw IndexError(IndexError::ParseError, "Parse error: cannot open " + fasta_path);
+    gzbuffer(gz, 1 << 20);
+    if (batch_size == 0) batch_size = 1000;
+    std::vector<std::pair<std::string, std::string>> batch; // (sequence, id)
+    size_t record_count = 0;
+    std::string line, id, seq;
+    bool have = false;
+    std::vector<char> buf(1 << 16);
+    auto flush_record = [&]() {
+        if (!have) return;
+        batch.emplace_back(std::move(seq), std::move(id));
+        seq.clear(); id.clear();
+        record_count++;
+        if (batch.size() >= batch_size) {
+            store_signatures(create_protein_signatures(batch, true));
+            batch.clear();
+        }
+        if (progress_interval > 0 && record_count % progress_interval == 0) printf("Read %zu sequences...\n", record_count);
+    };
+    try {
+        while (gzgets(gz, buf.data(), (int)buf.size())) {
+            line.assign(buf.data());
+            bool eol = !line.empty() && line.back() == '\n';
+            while (!eol && gzgets(gz, buf.data(), (int)buf.size())) { // long lines
+                line += buf.data();
+                eol = !line.empty() && line.back() == '\n';
+            }
+            while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+            if (line.empty()) continue;
+            if (line[0] == '>') {
+                flush_record();
+                id = line.substr(1);
+                have = true;
+            } else if (have) {
+                seq += line;
+            } else {
+                throw IndexError(IndexError::ParseError, "Parse error: FASTA record does not start with '>'");
+            }
+        }
+        flush_record();
+        if (!batch.empty()) store_signatures(create_protein_signatures(batch, true));
+    } catch (...) {
+        gzclose(gz);
+        throw;
+    }
+    gzclose(gz);
+    save_state();
+    if (progress_interval > 0) printf("Successfully processed and stored %zu sequences.\n", record_count);
+}
+
+// ---- persistence: flat little-endian file (own format; RocksDB layout is out of scope) --------------------
+static void put_u64(std::ostream &o, uint64_t v) { o.write((const char *)&v, 8); }
+static void put_str(std::ostream &o, const std::string &s) { put_u64(o, s.size()); o.write(s.data(), (std::streamsize)s.size()); }
+static uint64_t get_u64(std::istream &i) { uint64_t v = 0; i.read((char *)&v, 8); return v; }
+static std::string get_str(std::istream &i) { uint64_t n = get_u64(i); std::string s(n, '\0'); i.read(&s[0], (std::streamsize)n); return s; }
+
+void ProteomeIndex::save_state() {
+    std::ofstream o(path_, std::ios::binary | std::ios::trunc);
+    if (!o) throw IndexError(IndexError::Io, "IO error: cannot write " + path_);
+    o.write("KSIDX001", 8);
+    put_str(o, moltype_); put_u64(o, ksize_); put_u64(o, scaled_); put_u64(o, store_raw_ ? 1 : 0);
+    put_u64(o, combined_mins_.size());
+    o.write((const char *)combined_mins_.data(), (std::streamsize)(combined_mins_.size() * 8));
+    o.write((const char *)combined_abunds_.data(), (std::streamsize)(combined_abunds_.size() * 8));
+    put_u64(o, signatures_.size());
+    for (auto &kv : signatures_) {
+        const ProteinSignature &g = kv.second;
+        put_str(o, g.name); put_str(o, g.md5sum);
+        put_u64(o, g.mins.size());
+        o.write((const char *)g.mins.data(), (std::streamsize)(g.mins.size() * 8));
+        o.write((const char *)g.abunds.data(), (std::streamsize)(g.abunds.size() * 8));
+        put_u64(o, g.raw_sequence ? 1 : 0);
+        if (g.raw_sequence) put_str(o, *g.raw_sequence);
+        put_u64(o, g.kmer_infos.size());
+        for (auto &ki : g.kmer_infos) {
+            put_u64(o, ki.first); put_str(o, ki.second.encoded_kmer);
+            put_u64(o, ki.second.original_kmer_to_position.size());
+            for (auto &op : ki.second.original_kmer_to_position) {
+                put_str(o, op.first); put_u64(o, op.second.size());
+                for (size_t x : op.second) put_u64(o, x);
+            }
+        }
+    }
+    if (!o) throw IndexError(IndexError::Io, "IO error: short write to " + path_);
+}
+
+std::unique_ptr<ProteomeIndex> ProteomeIndex::load(const std::string &path, int device) {
+    std::ifstream i(path, std::ios::binary);
+    char magic[8] = {0};
+    if (!i || !i.read(magic, 8) || memcmp(magic, "KSIDX001", 8) != 0)
+        throw IndexError(IndexError::NoSavedState, "No saved state found in database"); // errors.rs:23-24
+    std::string moltype = get_str(i);
+    uint32_t k = (uint32_t)get_u64(i), sc = (uint32_t)get_u64(i);
+    bool raw = get_u64(i) != 0;
+    auto ix = std::make_unique<ProteomeIndex>(path, k, sc, moltype, raw, device);
+    uint64_t nc = get_u64(i);
+    ix->combined_mins_.resize(nc); ix->combined_abunds_.resize(nc);
+    i.read((char *)ix->combined_mins_.data(), (std::streamsize)(nc * 8));
+    i.read((char *)ix->combined_abunds_.data(), (std::streamsize)(nc * 8));
+    uint64_t ns = get_u64(i);
+    for (uint64_t s = 0; s < ns; s++) {
+        ProteinSignature g;
+        g.name = get_str(i); g.md5sum = get_str(i);
+        g.moltype = moltype; g.protein_ksize = k; g.scaled = sc;
+        uint64_t nm = get_u64(i);
+        g.mins.resize(nm); g.abunds.resize(nm);
+        i.read((char *)g.mins.data(), (std::streamsize)(nm * 8));
+        i.read((char *)g.abunds.data(), (std::streamsize)(nm * 8));
+        if (get_u64(i)) g.raw_sequence = get_str(i);
+        uint64_t nk = get_u64(i);
+        for (uint64_t q = 0; q < nk; q++) {
+            uint64_t h = get_u64(i);
+            KmerInfo &ki = g.kmer_infos[h];
+            ki.ksize = k; ki.hashval = h; ki.encoded_kmer = get_str(i);
+            uint64_t no = get_u64(i);
+            for (uint64_t o = 0; o < no; o++) {
+                std::string orig = get_str(i);
+                uint64_t np = get_u64(i);
+                auto &v = ki.original_kmer_to_position[orig];
+                for (uint64_t x = 0; x < np; x++) v.push_back((size_t)get_u64(i));
+            }
+        }
+        std::string key = g.md5sum;
+        ix->signatures_[key] = std::move(g);
+    }
+    if (!i) throw IndexError(IndexError::Io, "IO error: truncated index file " + path);
+    return ix;
+}
+
+bool ProteomeIndex::is_equivalent_to(const ProteomeIndex &o) const { // index.rs:524-625
+    if (ksize_ != o.ksize_ || scaled_ != o.scaled_ || moltype_ != o.moltype_) return false;
+    if (signature_count() != o.signature_count()) return false;
+    if (combined_minhash_size() != o.combined_minhash_size()) return false;
+    for (auto &kv : signatures_) {
+        auto it = o.signatures_.find(kv.first);
+        if (it == o.signatures_.end()) return false;
+        const ProteinSignature &a = kv.second, &b = it->second;
+        if (a.mins != b.mins) return false;
+        if (a.kmer_infos.size() != b.kmer_infos.size()) return false;
+        for (auto &ki : a.kmer_infos) {
+            auto jt = b.kmer_infos.find(ki.first);
+            if (jt == b.kmer_infos.end()) return false;
+            if (ki.second.ksize != jt->second.ksize || ki.second.hashval != jt->second.hashval ||
+                ki.second.encoded_kmer != jt->second.encoded_kmer ||
+                ki.second.original_kmer_to_position != jt->second.original_kmer_to_position)
+                return false;
+        }
+    }
+    return combined_mins_ == o.combined_mins_;
+}
+
+void ProteomeIndex::print_stats() const { // index.rs:628-639
+    printf("ProteomeIndex Statistics:\n  K-mer size: %u\n  Scaled: %u\n  Molecular type: %s\n  Combined minhash size: %zu\n"
+           "  Raw sequence storage: %s\n",
+           ksize_, scaled_, moltype_.c_str(), combined_minhash_size(), store_raw_ ? "enabled" : "disabled");
+}
+
+std::unique_ptr<ProteomeIndex> ProteomeIndexBuilder::build() const { // index.rs:3021-3036
+    if (!path_) throw IndexError(IndexError::BuilderError, "Builder error: Database path is required");
+    if (!ksize_) throw IndexError(IndexError::BuilderError, "Builder error: K-mer size is required");
+    if (!scaled_) throw IndexError(IndexError::BuilderError, "Builder error: Scaled value is required");
+    if (!moltype_) throw IndexError(IndexError::BuilderError, "Builder error: Molecular type is required");
+    return std::make_unique<ProteomeIndex>(*path_, *ksize_, *scaled_, *moltype_, store_raw_, device_);
+}
+
+std::unique_ptr<ProteomeIndex> ProteomeIndexBuilder::build_with_auto_filename() const { // index.rs:3039-3060
+    if (!path_) throw IndexError(IndexError::BuilderError, "Builder error: Base path is required");
+    if (!ksize_) throw IndexError(IndexError::BuilderError, "Builder error: K-mer size is required");
+    if (!scaled_) throw IndexError(IndexError::BuilderError, "Builder error: Scaled value is required");
+    if (!moltype_) throw IndexError(IndexError::BuilderError, "Builder error: Molecular type is required");
+    return ProteomeIndex::new_with_auto_filename(*path_, *ksize_, *scaled_, *moltype_, store_raw_, device_);
+}
+
+} // namespace kmerseek
+
+// =============================================================================================
+// flat C shim
+// =============================================================================================
+using kmerseek::IndexError;
+using kmerseek::ProteinSignature;
+using kmerseek::ProteomeIndex;
+
+struct ksh_index {
+    std::unique_ptr<ProteomeIndex> ix;
+};
+
+static int fail(const IndexError &e, char *err, size_t cap) {
+    if (err && cap) { strncpy(err, e.what(), cap - 1); err[cap - 1] = 0; }
+    return (int)e.kind + 1;
+}
+static int fail_std(const std::exception &e, char *err, size_t cap) {
+    if (err && cap) { strncpy(err, e.what(), cap - 1); err[cap - 1] = 0; }
+    return 1000;
+}
+#define KSH_GUARD(...)                                             \
+    try { __VA_ARGS__; return 0; }                                 \
+    catch (const IndexError &e) { return fail(e, err, err_cap); }  \
+    catch (const std::exception &e) { return fail_std(e, err, err_cap); }
+
+static void json_str(std::ostringstream &o, const std::string &s) {
+    o << '"';
+    for (unsigned char c : s) {
+        if (c == '"' || c == '\\') o << '\\' << c;
+        else if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o << b; }
+        else o << c;
+    }
+    o << '"';
+}
+
+static void json_sig(std::ostringstream &o, const ProteinSignature &g, bool with_kmers) {
+    o << "{\"name\":"; json_str(o, g.name);
+    o << ",\"md5sum\":"; json_str(o, g.md5sum);
+    o << ",\"moltype\":"; json_str(o, g.moltype);
+    o << ",\"protein_ksize\":" << g.protein_ksize << ",\"minhash_ksize\":" << g.minhash_ksize() << ",\"scaled\":" << g.scaled;
+    o << ",\"mins\":[";
+    for (size_t i = 0; i < g.mins.size(); i++) o << (i ? "," : "") << g.mins[i];
+    o << "],\"abunds\":[";
+    for (size_t i = 0; i < g.abunds.size(); i++) o << (i ? "," : "") << g.abunds[i];
+    o << "],\"n_kmer_infos\":" << g.kmer_infos.size();
+    o << ",\"raw_sequence\":";
+    if (g.raw_sequence) json_str(o, *g.raw_sequence); else o << "null";
+    if (with_kmers) {
+        o << ",\"kmer_infos\":{";
+        bool first = true;
+        for (auto &ki : g.kmer_infos) {
+            o << (first ? "" : ",") << '"' << ki.first << "\":{\"ksize\":" << ki.second.ksize << ",\"encoded_kmer\":";
+            json_str(o, ki.second.encoded_kmer);
+            o << ",\"original_kmer_to_position\":{";
+            bool f2 = true;
+            for (auto &op : ki.second.original_kmer_to_position) {
+                o << (f2 ? "" : ","); json_str(o, op.first); o << ":[";
+                for (size_t x = 0; x < op.second.size(); x++) o << (x ? "," : "") << op.second[x];
+                o << "]";
+                f2 = false;
+            }
+            o << "}}";
+            first = false;
+        }
+        o << "}";
+    }
+    o << "}";
+}
+
+static char *dup_string(const std::string &s) {
+    char *p = (char *)malloc(s.size() + 1);
+    if (p) memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+
+extern "C" {
+
+int ksh_index_new(const char *path, uint32_t ksize, uint32_t scaled, const char *moltype, int store_raw, int device,
+                  int auto_filename, ksh_index **out, char *err, size_t err_cap) {
+    KSH_GUARD({
+        auto h = new ksh_index();
+        try {
+            if (auto_filename) h->ix = ProteomeIndex::new_with_auto_filename(path, ksize, scaled, moltype, store_raw != 0, device);
+            else h->ix = std::make_unique<ProteomeIndex>(path, ksize, scaled, moltype, store_raw != 0, device);
+        } catch (...) { delete h; throw; }
+        *out = h;
+    })
+}
+
+int ksh_index_build(const char *path, int has_ksize, uint32_t ksize, int has_scaled, uint32_t scaled, const char *moltype,
+                    int store_raw, int auto_filename, int device, ksh_index **out, char *err, size_t err_cap) {
+    KSH_GUARD({
+        kmerseek::ProteomeIndexBuilder b = ProteomeIndex::builder();
+        if (path) b.path(path);
+        if (has_ksize) b.ksize(ksize);
+        if (has_scaled) b.scaled(scaled);
+        if (moltype) b.moltype(moltype);
+        b.store_raw_sequences(store_raw != 0).device(device);
+        auto h = new ksh_index();
+        try { h->ix = auto_filename ? b.build_with_auto_filename() : b.build(); } catch (...) { delete h; throw; }
+        *out = h;
+    })
+}
+
+void ksh_index_free(ksh_index *ix) { delete ix; }
+
+int ksh_index_create_signature(ksh_index *ix, const char *sequence, const char *name, int store, char **json_out,
+                               char *err, size_t err_cap) {
+    KSH_GUARD({
+        ProteinSignature g = ix->ix->create_protein_signature(sequence, name);
+        if (json_out) { std::ostringstream o; json_sig(o, g, true); *json_out = dup_string(o.str()); }
+        if (store) { std::vector<ProteinSignature> v; v.push_back(std::move(g)); ix->ix->store_signatures(std::move(v)); }
+    })
+}
+
+int ksh_index_add_records(ksh_index *ix, const char *const *sequences, const char *const *names, uint32_t n, int upper,
+                          char *err, size_t err_cap) {
+    KSH_GUARD({
+        std::vector<std::pair<std::string, std::string>> recs(n);
+        for (uint32_t i = 0; i < n; i++) recs[i] = {sequences[i], names[i]};
+        ix->ix->store_signatures(ix->ix->create_protein_signatures(recs, upper != 0));
+    })
+}
+
+int ksh_index_process_fasta(ksh_index *ix, const char *fasta_path, uint32_t progress_interval, uint64_t batch_size,
+                            char *err, size_t err_cap) {
+    KSH_GUARD(ix->ix->process_fasta(fasta_path, progress_interval, (size_t)batch_size))
+}
+
+uint64_t ksh_index_signature_count(const ksh_index *ix) { return ix->ix->signature_count(); }
+uint64_t ksh_index_combined_minhash_size(const ksh_index *ix) { return ix->ix->combined_minhash_size(); }
+uint32_t ksh_index_ksize(const ksh_index *ix) { return ix->ix->ksize(); }
+uint32_t ksh_index_scaled(const ksh_index *ix) { return ix->ix->scaled(); }
+int ksh_index_store_raw_sequences(const ksh_index *ix) { return ix->ix->store_raw_sequences() ? 1 : 0; }
+
+static int copy_out(const std::string &s, char *out, size_t cap) {
+    if (!out || !cap) return 1;
+    strncpy(out, s.c_str(), cap - 1);
+    out[cap - 1] = 0;
+    return 0;
+}
+int ksh_index_moltype(const ksh_index *ix, char *out, size_t cap) { return copy_out(ix->ix->moltype(), out, cap); }
+int ksh_index_path(const ksh_index *ix, char *out, size_t cap) { return copy_out(ix->ix->path(), out, cap); }
+int ksh_index_generate_filename(const ksh_index *ix, const char *base_name, char *out, size_t cap) {
+    return copy_out(ix->ix->generate_filename(base_name), out, cap);
+}
+
+int ksh_index_dump_json(const ksh_index *ix, int with_kmers, char **json_out) {
+    std::ostringstream o;
+    o << "{\"ksize\":" << ix->ix->ksize() << ",\"scaled\":" << ix->ix->scaled() << ",\"moltype\":";
+    json_str(o, ix->ix->moltype());
+    o << ",\"combined_mins\":[";
+    auto &cm = ix->ix->combined_mins();
+    for (size_t i = 0; i < cm.size(); i++) o << (i ? "," : "") << cm[i];
+    o << "],\"combined_abunds\":[";
+    auto &ca = ix->ix->combined_abunds();
+    for (size_t i = 0; i < ca.size(); i++) o << (i ? "," : "") << ca[i];
+    o << "],\"signatures\":{";
+    bool first = true;
+    for (auto &kv : ix->ix->get_signatures()) {
+        o << (first ? "" : ","); json_str(o, kv.first); o << ":";
+        json_sig(o, kv.second, with_kmers != 0);
+        first = false;
+    }
+    o << "}}";
+    *json_out = dup_string(o.str());
+    return *json_out ? 0 : 1;
+}
+
+int ksh_index_is_equivalent_to(const ksh_index *a, const ksh_index *b, int *equal, char *err, size_t err_cap) {
+    KSH_GUARD(*equal = a->ix->is_equivalent_to(*b->ix) ? 1 : 0)
+}
+
+int ksh_index_save_state(ksh_index *ix, char *err, size_t err_cap) { KSH_GUARD(ix->ix->save_state()) }
+
+int ksh_index_load(const char *path, int device, ksh_index **out, char *err, size_t err_cap) {
+    KSH_GUARD({
+        auto h = new ksh_index();
+        try { h->ix = ProteomeIndex::load(path, device); } catch (...) { delete h; throw; }
+        *out = h;
+    })
+}
+
+void ksh_string_free(char *s) { free(s); }
+
+} // extern "C"

@@ -377,3 +377,79 @@ done:
 #undef SE_CHECK
 #undef SE_HIP
 }
+
+// ---------------------------------------------------------------------------------------------
+// union of all sketches with summed abundances: the "combined minhash" of ProteomeIndex::store_signatures
+// (src/rust/index.rs:800-830, add_many_with_abund under a mutex there; here one sort + run-length reduce)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_union_emit(const u64 *keys, const u32 *vals, const u64 *row_start, u32 n_rows,
+                                                    u64 *hashes, u32 *abunds) {
+    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    u64 b = row_start[r], e = row_start[r + 1];
+    u64 w = 0;
+    for (u64 j = b; j < e; j++) w += vals[j];
+    hashes[r] = keys[b];
+    abunds[r] = w > 0xffffffffULL ? 0xffffffffu : (u32)w;
+}
+
+int ks_union_impl(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out) {
+    if (!in || !out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    ks_sketches *U = new ks_sketches();
+    memset(U, 0, sizeof *U);
+    U->ctx = ctx; U->params = in->params; U->n_seqs = 1; U->n_windows = in->n_windows;
+    const u64 n = in->n_hashes;
+    u64 *k0 = nullptr, *k1 = nullptr, *row_start = nullptr;
+    u32 *v0 = nullptr, *v1 = nullptr, *heads = nullptr, *d_nrows = nullptr;
+    int st = KS_OK;
+#define UN_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
+#define UN_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
+    UN_CHECK(ks_alloc(ctx, &U->d_offsets, 2));
+    if (n == 0) {
+        UN_HIP(hipMemsetAsync(U->d_offsets, 0, 2 * sizeof(u64), ctx->stream));
+        UN_CHECK(ks_alloc(ctx, &U->d_hashes, 1)); UN_CHECK(ks_alloc(ctx, &U->d_abunds, 1));
+        UN_HIP(hipStreamSynchronize(ctx->stream));
+        goto done;
+    }
+    {
+        UN_CHECK(ks_alloc(ctx, &k0, (size_t)n)); UN_CHECK(ks_alloc(ctx, &k1, (size_t)n));
+        UN_CHECK(ks_alloc(ctx, &v0, (size_t)n)); UN_CHECK(ks_alloc(ctx, &v1, (size_t)n));
+        const int shifts[8] = {0, 8, 16, 24, 32, 40, 48, 56};
+        u64 *ks = nullptr;
+        u32 *vs = nullptr;
+        UN_CHECK(ks_radix_sort_u32(ctx, KS_SORT_PAIRS, in->d_hashes, in->d_abunds, k0, v0, k1, v1, n, shifts, 8, &ks, &vs));
+        UN_CHECK(ks_alloc(ctx, &heads, (size_t)n));
+        UN_CHECK(ks_alloc(ctx, &d_nrows, 1));
+        const u32 g = (u32)((n + 255) / 256);
+        ks_timer_begin(ctx, "pair_heads");
+        hipLaunchKernelGGL(k_pair_heads, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)ks, n, heads);
+        ks_timer_end(ctx);
+        UN_CHECK(ks_scan_u32_inplace(ctx, heads, n, d_nrows));
+        UN_HIP(hipMemcpyAsync(ctx->h_pin, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        UN_HIP(hipStreamSynchronize(ctx->stream));
+        const u32 n_rows = *(u32 *)ctx->h_pin;
+        U->n_hashes = n_rows;
+        UN_CHECK(ks_alloc(ctx, &row_start, (size_t)n_rows + 1));
+        UN_CHECK(ks_alloc(ctx, &U->d_hashes, (size_t)n_rows)); UN_CHECK(ks_alloc(ctx, &U->d_abunds, (size_t)n_rows));
+        ks_timer_begin(ctx, "pair_rows");
+        hipLaunchKernelGGL(k_pair_rows, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)ks, (const u32 *)vs, (const u32 *)heads, n, n_rows, row_start);
+        ks_timer_end(ctx);
+        ks_timer_begin(ctx, "union_emit");
+        hipLaunchKernelGGL(k_union_emit, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream, (const u64 *)ks, (const u32 *)vs,
+                           (const u64 *)row_start, n_rows, U->d_hashes, U->d_abunds);
+        ks_timer_end(ctx);
+        UN_HIP(hipGetLastError());
+        ctx->h_pin[0] = 0; ctx->h_pin[1] = n_rows;
+        UN_HIP(hipMemcpyAsync(U->d_offsets, ctx->h_pin, 2 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        UN_HIP(hipStreamSynchronize(ctx->stream));
+    }
+done:
+    ks_pool_free(ctx, k0); ks_pool_free(ctx, k1); ks_pool_free(ctx, v0); ks_pool_free(ctx, v1);
+    ks_pool_free(ctx, heads); ks_pool_free(ctx, d_nrows); ks_pool_free(ctx, row_start);
+    if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_sketches_free(U); return st; }
+    *out = U;
+    return KS_OK;
+#undef UN_CHECK
+#undef UN_HIP
+}

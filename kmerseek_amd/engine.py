@@ -226,6 +226,12 @@ class Sketches(_Owned):
     def n_windows(self) -> int:
         return int(self._ctx._L.ks_sketches_n_windows(self._h))
 
+    def union(self) -> "Sketches":
+        """Combined sketch: sorted unique hashes of all sequences with summed abundances (one sequence)."""
+        out = C.c_void_p()
+        self._ctx._check(self._ctx._L.ks_sketches_union(self._ctx._h, self._h, C.byref(out)))
+        return Sketches(self._ctx, out)
+
     def to_host(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         n, m = self.n_seqs, self.n_hashes
         offs = np.zeros(n + 1, np.uint64); hashes = np.zeros(m, np.uint64); abunds = np.zeros(m, np.uint32)

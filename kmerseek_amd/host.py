@@ -1,0 +1,280 @@
+"""Python surface of the reference's Rust crate, bound to the C++ host mirror through include/kmerseek_host_c.h.
+
+Mirrors the PyO3 module of src/rust/lib.rs:28-103 — ``sum_as_string``, ``PyProteinEncoding`` (Raw / Dayhoff / HP with
+classmethods raw() / dayhoff() / hp()), ``PyProteomeIndex(ksize, scaled, moltype, db_path)`` whose failures surface as
+``RuntimeError(str(e))`` — and adds ``ProteomeIndex`` / ``ProteomeIndexBuilder`` wrappers with the Rust method names
+(src/rust/index.rs:104-1017, 2975-3061) so the reference's index tests translate line by line.
+All computation happens in the HIP library; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import json
+from typing import Dict, List, Optional, Sequence, Tuple
+
+from . import _lib
+
+_ERR_CAP = 1024
+
+HOST_SIGNATURES = {
+    "ksh_index_new": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "ksh_index_build": (C.c_int, [C.c_char_p, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_char_p, C.c_int, C.c_int,
+                                  C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "ksh_index_free": (None, [C.c_void_p]),
+    "ksh_index_create_signature": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p),
+                                             C.c_char_p, C.c_size_t]),
+    "ksh_index_add_records": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint32, C.c_int,
+                                        C.c_char_p, C.c_size_t]),
+    "ksh_index_process_fasta": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_char_p, C.c_size_t]),
+    "ksh_index_signature_count": (C.c_uint64, [C.c_void_p]),
+    "ksh_index_combined_minhash_size": (C.c_uint64, [C.c_void_p]),
+    "ksh_index_ksize": (C.c_uint32, [C.c_void_p]),
+    "ksh_index_scaled": (C.c_uint32, [C.c_void_p]),
+    "ksh_index_store_raw_sequences": (C.c_int, [C.c_void_p]),
+    "ksh_index_moltype": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "ksh_index_path": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "ksh_index_generate_filename": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "ksh_index_dump_json": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "ksh_index_is_equivalent_to": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "ksh_index_save_state": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "ksh_index_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "ksh_string_free": (None, [C.c_void_p]),
+}
+
+_bound = None
+
+
+def _host():
+    global _bound
+    if _bound is None:
+        L = _lib.load()
+        for name, (res, args) in HOST_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _bound = L
+    return _bound
+
+
+class IndexError_(RuntimeError):
+    """kmerseek::IndexError (src/rust/errors.rs); str() is the reference's Display text."""
+
+    KINDS = ["Database", "InvalidMoltype", "InvalidAminoAcid", "InvalidKsize", "NoSavedState", "Io", "Utf8",
+             "FastaParsing", "BuilderError", "SourmashError", "ParseError", "ValidationError", "Gpu"]
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+        self.kind = self.KINDS[code - 1] if 1 <= code <= len(self.KINDS) else "Other"
+
+
+def _call(fn, *args):
+    err = C.create_string_buffer(_ERR_CAP)
+    rc = fn(*args, err, _ERR_CAP)
+    if rc != 0:
+        raise IndexError_(rc, err.value.decode(errors="replace"))
+
+
+def _take_string(L, p: C.c_void_p) -> str:
+    try:
+        return C.string_at(p).decode()
+    finally:
+        L.ksh_string_free(p)
+
+
+def sum_as_string(a: int, b: int) -> str:
+    """src/rust/lib.rs:69-72"""
+    return str(a + b)
+
+
+class PyProteinEncoding(enum.Enum):
+    """src/rust/lib.rs:29-65"""
+    Raw = "protein"
+    Dayhoff = "dayhoff"
+    HP = "hp"
+
+    @classmethod
+    def raw(cls):
+        return cls.Raw
+
+    @classmethod
+    def dayhoff(cls):
+        return cls.Dayhoff
+
+    @classmethod
+    def hp(cls):
+        return cls.HP
+
+    def __str__(self):
+        return self.value
+
+
+class ProteomeIndex:
+    """kmerseek::ProteomeIndex — the C++ mirror of src/rust/index.rs:104-1017, method for method."""
+
+    def __init__(self, path: str, ksize: int, scaled: int, moltype: str, store_raw_sequences: bool = False,
+                 device: int = 0, _handle=None):
+        self._L = _host()
+        if _handle is not None:
+            self._h = _handle
+            return
+        h = C.c_void_p()
+        _call(self._L.ksh_index_new, str(path).encode(), ksize, scaled, str(moltype).encode(),
+              1 if store_raw_sequences else 0, device, 0, C.byref(h))
+        self._h = h
+
+    # -- constructors ------------------------------------------------------------------------------
+    @classmethod
+    def new(cls, path, ksize, scaled, moltype, store_raw_sequences=False, device=0):
+        return cls(path, ksize, scaled, moltype, store_raw_sequences, device)
+
+    @classmethod
+    def new_with_auto_filename(cls, base_path, ksize, scaled, moltype, store_raw_sequences=False, device=0):
+        L = _host()
+        h = C.c_void_p()
+        _call(L.ksh_index_new, str(base_path).encode(), ksize, scaled, str(moltype).encode(),
+              1 if store_raw_sequences else 0, device, 1, C.byref(h))
+        return cls(None, 0, 0, "", _handle=h)
+
+    @classmethod
+    def builder(cls) -> "ProteomeIndexBuilder":
+        return ProteomeIndexBuilder()
+
+    @classmethod
+    def load(cls, path, device=0):
+        L = _host()
+        h = C.c_void_p()
+        _call(L.ksh_index_load, str(path).encode(), device, C.byref(h))
+        return cls(None, 0, 0, "", _handle=h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ksh_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the path -----------------------------------------------------------------------------------
+    def create_protein_signature(self, sequence: str, name: str, store: bool = False) -> dict:
+        out = C.c_void_p()
+        _call(self._L.ksh_index_create_signature, self._h, sequence.encode(), name.encode(), 1 if store else 0,
+              C.byref(out))
+        sig = json.loads(_take_string(self._L, out))
+        sig["kmer_infos"] = {int(k): v for k, v in sig["kmer_infos"].items()}
+        return sig
+
+    def add_records(self, records: Sequence[Tuple[str, str]], upper: bool = False) -> None:
+        """create_protein_signatures + store_signatures_batch for (sequence, name) records."""
+        n = len(records)
+        seqs = (C.c_char_p * n)(*[r[0].encode() for r in records])
+        names = (C.c_char_p * n)(*[r[1].encode() for r in records])
+        _call(self._L.ksh_index_add_records, self._h, seqs, names, n, 1 if upper else 0)
+
+    def process_fasta(self, fasta_path, progress_interval: int = 0, batch_size: int = 1000) -> None:
+        _call(self._L.ksh_index_process_fasta, self._h, str(fasta_path).encode(), progress_interval, batch_size)
+
+    def save_state(self) -> None:
+        _call(self._L.ksh_index_save_state, self._h)
+
+    # -- getters ------------------------------------------------------------------------------------
+    def signature_count(self) -> int:
+        return int(self._L.ksh_index_signature_count(self._h))
+
+    def combined_minhash_size(self) -> int:
+        return int(self._L.ksh_index_combined_minhash_size(self._h))
+
+    def ksize(self) -> int:
+        return int(self._L.ksh_index_ksize(self._h))
+
+    def scaled(self) -> int:
+        return int(self._L.ksh_index_scaled(self._h))
+
+    def store_raw_sequences(self) -> bool:
+        return bool(self._L.ksh_index_store_raw_sequences(self._h))
+
+    def _str(self, fn, *args) -> str:
+        buf = C.create_string_buffer(4096)
+        fn(self._h, *args, buf, 4096)
+        return buf.value.decode()
+
+    def moltype(self) -> str:
+        return self._str(self._L.ksh_index_moltype)
+
+    def path(self) -> str:
+        return self._str(self._L.ksh_index_path)
+
+    def generate_filename(self, base_name: str) -> str:
+        return self._str(self._L.ksh_index_generate_filename, base_name.encode())
+
+    def dump(self, with_kmers: bool = True) -> dict:
+        out = C.c_void_p()
+        if self._L.ksh_index_dump_json(self._h, 1 if with_kmers else 0, C.byref(out)) != 0:
+            raise IndexError_(1000, "dump failed")
+        d = json.loads(_take_string(self._L, out))
+        if with_kmers:
+            for s in d["signatures"].values():
+                s["kmer_infos"] = {int(k): v for k, v in s["kmer_infos"].items()}
+        return d
+
+    def get_signatures(self) -> Dict[str, dict]:
+        return self.dump(True)["signatures"]
+
+    def is_equivalent_to(self, other: "ProteomeIndex") -> bool:
+        eq = C.c_int(0)
+        _call(self._L.ksh_index_is_equivalent_to, self._h, other._h, C.byref(eq))
+        return bool(eq.value)
+
+
+class ProteomeIndexBuilder:
+    """src/rust/index.rs:2975-3061"""
+
+    def __init__(self):
+        self._path = self._moltype = None
+        self._ksize = self._scaled = None
+        self._raw = False
+        self._device = 0
+
+    def path(self, p):
+        self._path = str(p); return self
+
+    def ksize(self, k):
+        self._ksize = int(k); return self
+
+    def scaled(self, s):
+        self._scaled = int(s); return self
+
+    def moltype(self, m):
+        self._moltype = str(m); return self
+
+    def store_raw_sequences(self, b):
+        self._raw = bool(b); return self
+
+    def device(self, d):
+        self._device = int(d); return self
+
+    def _build(self, auto: int) -> ProteomeIndex:
+        L = _host()
+        h = C.c_void_p()
+        _call(L.ksh_index_build, self._path.encode() if self._path is not None else None,
+              1 if self._ksize is not None else 0, self._ksize or 0, 1 if self._scaled is not None else 0,
+              self._scaled or 0, self._moltype.encode() if self._moltype is not None else None,
+              1 if self._raw else 0, auto, self._device, C.byref(h))
+        return ProteomeIndex(None, 0, 0, "", _handle=h)
+
+    def build(self) -> ProteomeIndex:
+        return self._build(0)
+
+    def build_with_auto_filename(self) -> ProteomeIndex:
+        return self._build(1)
+
+
+class PyProteomeIndex:
+    """src/rust/lib.rs:74-92: constructor only; any failure -> RuntimeError(str(e))."""
+
+    def __init__(self, ksize: int, scaled: int, moltype, db_path: str):
+        self.index = ProteomeIndex(db_path, ksize, scaled, str(moltype), False)

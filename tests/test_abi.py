@@ -20,10 +20,10 @@ def lib():
     return _lib.load()
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "kmerseek_amd.h")).read()
+def declared_functions(header="kmerseek_amd.h", prefix="ks_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ks_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_all_exported(lib):
@@ -33,6 +33,15 @@ def test_header_symbols_all_exported(lib):
         assert hasattr(lib, n), f"{n} declared in include/kmerseek_amd.h but not exported"
     # and the ctypes table covers exactly the header
     assert sorted(_lib.SIGNATURES) == names
+
+
+def test_host_shim_symbols_all_exported(lib):
+    from kmerseek_amd import host
+    names = declared_functions("kmerseek_host_c.h", "ksh_")
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/kmerseek_host_c.h but not exported"
+    assert sorted(host.HOST_SIGNATURES) == names
 
 
 def test_struct_layouts_match_header():

@@ -1,0 +1,236 @@
+"""The reference's own index / entity / search tests, translated to the C++ host mirror (kmerseek_amd/host.py over
+include/kmerseek_host_c.h) and the wire-format layer.  Each test names the reference test it follows.  GPU only:
+every signature comes out of the HIP library."""
+import csv
+import gzip
+import math
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import kmerseek_amd as ks
+from kmerseek_amd import host, wire
+from oracle import oracle
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+BCL2 = "bcl2_first25_uniprotkb_accession_O43236_OR_accession_2025_02_06.fasta.gz"
+TEST_PROTEIN = "PLANTANDANIMALGENQMES"
+TEST_FASTA_CONTENT = ">test_protein1\nPLANTANDANIMALGENQMES\n>test_protein2\nLIVINGALIVE"
+
+
+def new_index(tmp_path, k, scaled, mol, raw=False, name="test.db"):
+    return host.ProteomeIndex(str(tmp_path / name), k, scaled, mol, raw)
+
+
+# src/rust/index.rs:1041-1135, 1138-1250, 1253-1380 (test_process_kmers_moltype_*)
+@pytest.mark.parametrize("mol", ["protein", "dayhoff", "hp"])
+def test_process_kmers_moltype(tmp_path, hash_kats, mol):
+    ix = new_index(tmp_path, 5, 1, mol)
+    sig = ix.create_protein_signature(TEST_PROTEIN, "test_protein")
+    rows = hash_kats[mol]
+    assert len(sig["kmer_infos"]) == len(rows) == {"protein": 17, "dayhoff": 17, "hp": 14}[mol]
+    assert sig["mins"] == sorted(r["hash"] for r in rows)
+    for r in rows:
+        info = sig["kmer_infos"][r["hash"]]
+        assert info["encoded_kmer"] == r["encoded"] and info["ksize"] == 5
+        assert info["original_kmer_to_position"] == r["originals"]
+    assert sig["minhash_ksize"] == 15 and sig["name"] == "test_protein"
+
+
+# src/rust/index.rs:1548-1730 (test_process_fasta_moltype_*)
+def test_process_fasta_small(tmp_path, index_kats):
+    fasta = tmp_path / "test.fasta"
+    fasta.write_text(TEST_FASTA_CONTENT)
+    for case in index_kats["small_fasta"]["cases"]:
+        ix = new_index(tmp_path, case["ksize"], case["scaled"], case["moltype"], name=f"{case['moltype']}.db")
+        ix.process_fasta(fasta, 0, 1000)
+        sigs = ix.get_signatures()
+        assert len(sigs) == 2 == ix.signature_count()
+        assert {k: len(v["kmer_infos"]) for k, v in sigs.items()} == case["keys"]
+        assert ix.combined_minhash_size() == case["combined"]
+
+
+# src/rust/index.rs:1791-1970 (test_process_fasta_gz_moltype_*), :2390-2450 (manual vs auto)
+def test_process_fasta_gz_bcl2(tmp_path, index_kats):
+    fasta = os.path.join(GOLDEN, BCL2)
+    for case in index_kats["bcl2_first25"]["cases"]:
+        ix = new_index(tmp_path, case["ksize"], case["scaled"], case["moltype"], name=f"bcl2.{case['moltype']}.{case['ksize']}.db")
+        ix.process_fasta(fasta, 0, 1000)
+        assert ix.signature_count() == 25
+        sigs = ix.get_signatures()
+        for key, n in case["keys"].items():
+            assert len(sigs[key]["kmer_infos"]) == n
+        assert ix.combined_minhash_size() == case["combined"]
+    # small batches give the same index as one big batch
+    a = new_index(tmp_path, 16, 5, "hp", name="a.db"); a.process_fasta(fasta, 0, 7)
+    b = new_index(tmp_path, 16, 5, "hp", name="b.db"); b.process_fasta(fasta, 0, 100000)
+    assert a.is_equivalent_to(b) and a.combined_minhash_size() == 1603
+    # auto filename (index.rs:2426-2448)
+    local = tmp_path / BCL2
+    shutil.copyfile(fasta, local)
+    auto = host.ProteomeIndex.new_with_auto_filename(str(local), 16, 5, "hp", False)
+    assert auto.path() == str(local) + ".hp.k16.scaled5.kmerseek.rocksdb"
+    auto.process_fasta(local, 0, 1000)
+    assert auto.is_equivalent_to(b)
+
+
+# src/rust/index.rs:1975-2076, 2079-2250 (amino-acid validation, ambiguity)
+def test_amino_acid_validation(tmp_path, index_kats, hash_kats):
+    ix = new_index(tmp_path, 5, 1, "protein")
+    for s in index_kats["single"]:
+        sig = ix.create_protein_signature(s["sequence"], "test_protein")
+        assert sig["md5sum"] == s["key"] and len(sig["kmer_infos"]) == s["n_kmers"]
+    assert len(ix.create_protein_signature("ACDEFXBZJ", "t")["kmer_infos"]) == 5
+    for case in index_kats["invalid"]:
+        with pytest.raises(RuntimeError) as e:
+            ix.create_protein_signature(case["sequence"], "test_protein")
+        assert case["message"] in str(e.value) and "position 18" in str(e.value)
+    for seq in ("PLANTANDANIMALGENBMES", "PLANTANDANIMALGENZMES", "PLANTANDANIMALGENJMES"):
+        assert len(ix.create_protein_signature(seq, "t")["kmer_infos"]) == 17
+    # lower case is only accepted on the FASTA path (index.rs:1000)
+    with pytest.raises(RuntimeError):
+        ix.create_protein_signature("plantandanimal", "t")
+    for a in hash_kats["ambiguity"]:
+        jx = new_index(tmp_path, 5, 1, a["moltype"], name=f"amb.{a['moltype']}.db")
+        sig = jx.create_protein_signature(a["sequence"], "test_protein")
+        assert len(sig["kmer_infos"]) == a["n_kmers"]
+        assert sig["kmer_infos"][a["hash"]]["encoded_kmer"] == a["encoded"]
+
+
+# src/rust/index.rs:2251-2300 (test_process_fasta_amino_acid_validation): one bad record fails the whole file
+def test_process_fasta_invalid_record_aborts(tmp_path):
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">ok1\nPLANTANDANIMALGENQMES\n>bad\nPLANTANDANIMALGEN1MES\n>ok2\nLIVINGALIVE\n")
+    ix = new_index(tmp_path, 5, 1, "protein")
+    with pytest.raises(RuntimeError) as e:
+        ix.process_fasta(bad, 0, 1000)
+    assert "Invalid amino acid '1'" in str(e.value)
+    assert ix.signature_count() == 0
+    good = tmp_path / "good.fasta"
+    good.write_text(">a\nPLANTANDANIMALGENQMES\n>b\nLIVINGALIVE\n>c\nACDEFGHIKLMNPQRSTVWY\n>d\nMKVLAAGIVGLCAK\n")
+    ix.process_fasta(good, 0, 2)
+    assert ix.signature_count() == 4
+
+
+# src/rust/index.rs:2337-2368, 2543-2593 (equivalence)
+def test_index_equivalence(tmp_path):
+    recs = [("PLANTANDANIMALGENQMES", "p1"), ("LIVINGALIVE", "p2"), ("ACDEFGHIKLMNPQRSTVWY", "p3")]
+    a = new_index(tmp_path, 5, 1, "protein", name="1.db"); a.add_records(recs)
+    b = new_index(tmp_path, 5, 1, "protein", name="2.db"); b.add_records(recs)
+    assert a.is_equivalent_to(b) and a.signature_count() == b.signature_count() == 3
+    assert a.combined_minhash_size() == b.combined_minhash_size() == 40
+    c = new_index(tmp_path, 10, 1, "protein", name="3.db"); c.add_records(recs)
+    assert not a.is_equivalent_to(c)
+    d = new_index(tmp_path, 5, 1, "protein", name="4.db"); d.add_records(recs[:2] + [("MKVLAAGIVGLCAKWWW", "p3")])
+    assert not a.is_equivalent_to(d)
+
+
+# src/rust/index.rs:2454-2477, 2596-2637 (filename generation) + builder errors (:3021-3060)
+def test_filenames_and_builder(tmp_path, index_kats):
+    for k, s, mol, want in index_kats["filenames"]:
+        ix = host.ProteomeIndex.new_with_auto_filename(str(tmp_path / "test.fasta"), k, s, mol, False)
+        assert os.path.basename(ix.path()) == want
+        assert ix.generate_filename("test.fasta") == want
+        assert (ix.ksize(), ix.scaled(), ix.moltype()) == (k, s, mol)
+    b = host.ProteomeIndex.builder().path(tmp_path / "b.db").ksize(5).scaled(1).moltype("protein").build()
+    assert b.ksize() == 5 and not b.store_raw_sequences()
+    for build, msg in (
+        (lambda: host.ProteomeIndex.builder().ksize(5).scaled(1).moltype("hp").build(), "Database path is required"),
+        (lambda: host.ProteomeIndex.builder().path("x").scaled(1).moltype("hp").build(), "K-mer size is required"),
+        (lambda: host.ProteomeIndex.builder().path("x").ksize(5).moltype("hp").build(), "Scaled value is required"),
+        (lambda: host.ProteomeIndex.builder().path("x").ksize(5).scaled(1).build(), "Molecular type is required"),
+        (lambda: host.ProteomeIndex.builder().ksize(5).scaled(1).moltype("hp").build_with_auto_filename(), "Base path is required"),
+    ):
+        with pytest.raises(RuntimeError) as e:
+            build()
+        assert msg in str(e.value) and e.value.kind == "BuilderError"
+    with pytest.raises(RuntimeError) as e:
+        host.ProteomeIndex(str(tmp_path / "m.db"), 5, 1, "dna", False)
+    assert "Invalid moltype: dna" in str(e.value)
+
+
+# src/rust/index.rs:2713-2845 (raw-sequence storage), :2847-2934 (mixed case), save/load round trip
+def test_raw_sequences_mixed_case_and_persistence(tmp_path, index_kats):
+    ix = new_index(tmp_path, 5, 1, "protein", raw=True)
+    sig = ix.create_protein_signature("ACDEFGHIKLMNPQRSTVWY", "t", store=True)
+    assert sig["raw_sequence"] == "ACDEFGHIKLMNPQRSTVWY" and ix.store_raw_sequences() and ix.signature_count() == 1
+    jx = new_index(tmp_path, 5, 1, "protein", raw=False, name="noraw.db")
+    assert jx.create_protein_signature("ACDEFGHIKLMNPQRSTVWY", "t")["raw_sequence"] is None
+    mc = index_kats["mixed_case"]
+    fasta = tmp_path / "mixed.fasta"
+    fasta.write_text("".join(f">{n}\n{s}\n" for n, s in mc["records"]))
+    mx = new_index(tmp_path, mc["ksize"], mc["scaled"], mc["moltype"], raw=True, name="mixed.db")
+    mx.process_fasta(fasta, 0, 1000)
+    sigs = mx.get_signatures()
+    counts = [len(s["kmer_infos"]) for s in sigs.values()]
+    assert len(sigs) == 2 and mc["short_kmers"] in counts and any(c > mc["min_long_kmers"] for c in counts)
+    assert all(s["raw_sequence"] == s["raw_sequence"].upper() for s in sigs.values())
+    # process_fasta saved the state: loading gives an equivalent index; an empty path has no saved state
+    back = host.ProteomeIndex.load(mx.path())
+    assert back.is_equivalent_to(mx) and back.store_raw_sequences()
+    with pytest.raises(RuntimeError) as e:
+        host.ProteomeIndex.load(str(tmp_path / "nothing.db"))
+    assert "No saved state found in database" in str(e.value)
+
+
+# src/rust/lib.rs:28-103
+def test_pyo3_surface(tmp_path):
+    assert host.sum_as_string(2, 3) == "5"
+    assert str(host.PyProteinEncoding.raw()) == "protein" and str(host.PyProteinEncoding.dayhoff()) == "dayhoff"
+    assert str(host.PyProteinEncoding.hp()) == "hp"
+    p = host.PyProteomeIndex(16, 5, host.PyProteinEncoding.hp(), str(tmp_path / "py.db"))
+    assert p.index.moltype() == "hp"
+    with pytest.raises(RuntimeError):
+        host.PyProteomeIndex(16, 5, "nope", str(tmp_path / "py2.db"))
+
+
+# tests/test_entity.py:9-22 (the sketch artifact equals the committed golden .sig.zip)
+@pytest.mark.parametrize("key,ksize", [("hp.k24.scaled5", 24), ("hp.k16.scaled5", 16), ("hp.k15.scaled5", 15)])
+def test_sketch_sig_zip_equals_golden(tmp_path, golden_sketches, key, ksize):
+    fasta = tmp_path / BCL2
+    shutil.copyfile(os.path.join(GOLDEN, BCL2), fasta)
+    sig = wire.sketch(str(fasta), "hp", ksize, 5)
+    assert sig == f"{fasta}.hp.k{ksize}.scaled5.sig.zip" and os.path.exists(sig)
+    assert os.path.exists(f"{fasta}.manysketch.csv")
+    names, offs, mins, abunds, k, sc, mol = wire.read_sig_zip(sig)
+    assert (k, sc, mol) == (ksize, 5, "hp")
+    gold = {s["name"]: s for s in golden_sketches[key]["signatures"]}
+    assert len(names) == 25
+    import zipfile, json
+    z = zipfile.ZipFile(sig)
+    for i, n in enumerate(names):
+        g = gold[n]
+        assert mins[int(offs[i]):int(offs[i + 1])].tolist() == g["mins"]
+        assert abunds[int(offs[i]):int(offs[i + 1])].tolist() == g["abundances"]
+        doc = json.loads(gzip.decompress(z.read(f"signatures/{g['md5sum']}.sig.gz")))
+        s = doc[0]["signatures"][0]
+        for f in ("num", "ksize", "seed", "max_hash", "md5sum", "molecule"):
+            assert s[f] == g[f]
+        assert doc[0]["hash_function"] == g["hash_function"]
+
+
+# tests/test_search.py:9-60 (the manysearch CSV equals the 5 expected rows, all 22 columns)
+def test_manysearch_csv_equals_expected(tmp_path, search_expected):
+    q = tmp_path / "ced9.fasta"
+    t = tmp_path / BCL2
+    shutil.copyfile(os.path.join(GOLDEN, "ced9.fasta"), q)
+    shutil.copyfile(os.path.join(GOLDEN, BCL2), t)
+    with ks.Context(0) as ctx:
+        qs = wire.sketch(str(q), "hp", 16, 5, ctx)
+        ts = wire.sketch(str(t), "hp", 16, 5, ctx)
+        out = tmp_path / "search.csv"
+        n = wire.do_manysearch(qs, ts, str(out), 16, 5, "hp", ctx)
+    assert n == 5
+    got = sorted(csv.DictReader(open(out)), key=lambda r: r["match_name"])
+    exp = sorted(search_expected["manysearch_rows"], key=lambda r: r["match_name"])
+    assert list(got[0].keys()) == search_expected["manysearch_columns"]
+    for g, w in zip(got, exp):
+        for col in search_expected["manysearch_columns"]:
+            if col in ("query_name", "query_md5", "match_name", "match_md5", "moltype"):
+                assert g[col] == w[col], col
+            else:
+                assert math.isclose(float(g[col]), float(w[col]), rel_tol=1e-12, abs_tol=1e-15), (col, g[col], w[col])
