@@ -1,0 +1,121 @@
+"""BASELINE.json configs[1], [2], [4] as parity-test cases at (or near) their stated sizes: full oracle comparison where
+the pairwise CPU search finishes in seconds, otherwise oracle on a query sample plus size-independent properties
+(symmetry of all-vs-all, self hits, (qid, tid) order, N-shard == 1-shard)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import kmerseek_amd as ks
+from kmerseek_amd import dist as ksd, synth
+from oracle import oracle
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = ks.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_search(ctx, q, t, k, scaled, mol):
+    T = ctx.sketch_batch(t[0], t[1], k, scaled, mol)
+    Q = ctx.sketch_batch(q[0], q[1], k, scaled, mol)
+    return Q, T, ctx.search(ctx.index_build(T), Q).to_host()
+
+
+def oracle_hits_for(q_sk, t_sk, qids):
+    qo, qm, _ = q_sk
+    to, tm, ta = t_sk
+    sub_off = np.zeros(len(qids) + 1, np.uint64)
+    parts = []
+    for i, q in enumerate(qids):
+        parts.append(qm[int(qo[q]):int(qo[q + 1])])
+        sub_off[i + 1] = sub_off[i] + len(parts[-1])
+    sub = np.concatenate(parts) if parts else np.zeros(0, np.uint64)
+    oq, ot, oi, ow = oracle.manysearch(sub_off, sub, to, tm, ta, n_threads=16)
+    return np.asarray(qids, np.uint32)[oq], ot, oi, ow
+
+
+def test_config2_10k_vs_10k_protein_k7(ctx):
+    """configs[1]: 10k synthetic proteins vs 10k index, k=7 scaled=1 protein — full pairwise oracle."""
+    t = synth.proteome(10000, stream=20)
+    q = synth.queries(10000, t[0], t[1], stream=21)
+    Q, T, got = gpu_search(ctx, q, t, 7, 1, "protein")
+    want_t = oracle.sketch_batch(t[0], t[1], 7, 1, "protein", n_threads=16)
+    want_q = oracle.sketch_batch(q[0], q[1], 7, 1, "protein", n_threads=16)
+    for g, w in zip(T.to_host() + Q.to_host(), want_t + want_q):
+        assert np.array_equal(g, w)
+    want = oracle.manysearch(want_q[0], want_q[1], want_t[0], want_t[1], want_t[2], n_threads=16)
+    assert len(want[0]) > 2000
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+
+
+def test_config3_100k_vs_100k_dayhoff_k16_s5(ctx):
+    """configs[2]: Dayhoff k=16 scaled=5, 100k-vs-100k — sketches vs oracle in full, search vs oracle on a query sample."""
+    t = synth.proteome(100000, stream=30)
+    q = synth.queries(100000, t[0], t[1], stream=31)
+    Q, T, got = gpu_search(ctx, q, t, 16, 5, "dayhoff")
+    want_t = oracle.sketch_batch(t[0], t[1], 16, 5, "dayhoff", n_threads=16)
+    want_q = oracle.sketch_batch(q[0], q[1], 16, 5, "dayhoff", n_threads=16)
+    for g, w in zip(T.to_host() + Q.to_host(), want_t + want_q):
+        assert np.array_equal(g, w)
+    qid, tid, isect, nw = got
+    key = qid.astype(np.uint64) << np.uint64(32) | tid.astype(np.uint64)
+    assert np.all(key[1:] > key[:-1])
+    sample = list(range(0, 20000, 97)) + list(range(20000, 100000, 1999))  # related queries come first
+    oq, ot, oi, ow = oracle_hits_for(want_q, want_t, sample)
+    sel = np.isin(qid, np.asarray(sample, np.uint32))
+    assert np.array_equal(qid[sel], oq) and np.array_equal(tid[sel], ot)
+    assert np.array_equal(isect[sel], oi) and np.array_equal(nw[sel], ow)
+    assert len(oq) > 150
+
+
+def test_config5_all_vs_all_hp_k24_sharded(ctx):
+    """configs[4] shape (hp k=24, all-vs-all, index sharded by target id) at 30k proteins: symmetry, self hits, and
+    8 target shards concatenated == unsharded; oracle on a query sample."""
+    n = 30000
+    p = synth.proteome(n, stream=40)
+    k, scaled, mol = 24, 5, "hp"
+    S = ctx.sketch_batch(p[0], p[1], k, scaled, mol)
+    full = ctx.search(ctx.index_build(S), S).to_host()
+    qid, tid, isect, nw = full
+    o, m, a = S.to_host()
+    sizes = (o[1:] - o[:-1]).astype(np.int64)
+    # self hits carry the sketch size
+    diag = qid == tid
+    assert np.array_equal(np.sort(qid[diag]), np.flatnonzero(sizes > 0).astype(np.uint32))
+    assert np.array_equal(isect[diag], sizes[qid[diag]].astype(np.uint32))
+    # intersect is symmetric: the (t, q) row exists with the same count
+    fwd = dict(zip(zip(qid.tolist(), tid.tolist()), isect.tolist()))
+    assert all(fwd[(t_, q_)] == i_ for (q_, t_), i_ in list(fwd.items())[:20000])
+    # index sharded by target id, 8 ways, hit lists concatenated (the exchange is a pure concatenation)
+    parts = []
+    for s0, s1 in ksd.shard_by_residues(p[1], 8):
+        sub = ksd.slice_batch(p[0], p[1], s0, s1)
+        Ti = ctx.sketch_batch(sub[0], sub[1], k, scaled, mol)
+        h = ctx.search(ctx.index_build(Ti), S).to_host()
+        parts.append(ksd.all_gather_hits(h, tid_base=s0))
+    rows = np.concatenate([np.stack([x.astype(np.int64) for x in part], axis=1) for part in parts])
+    rows = rows[np.lexsort((rows[:, 1], rows[:, 0]))]
+    assert np.array_equal(rows[:, 0], qid) and np.array_equal(rows[:, 1], tid)
+    assert np.array_equal(rows[:, 2], isect) and np.array_equal(rows[:, 3].astype(np.uint64), nw)
+    # oracle on a sample of queries
+    sample = list(range(0, n, 211))
+    oq, ot, oi, ow = oracle_hits_for((o, m, a), (o, m, a), sample)
+    sel = np.isin(qid, np.asarray(sample, np.uint32))
+    assert np.array_equal(qid[sel], oq) and np.array_equal(tid[sel], ot) and np.array_equal(isect[sel], oi)
+    assert np.array_equal(nw[sel], ow)
+
+
+def test_dist_layer_single_rank_gpu(ctx):
+    """The sharding layer driven by the HIP search function (world size 1 here; 2-rank logic: tests/test_dist_gloo.py)."""
+    t = synth.proteome(800, stream=60)
+    q = synth.queries(600, t[0], t[1], stream=61)
+    fn = ksd.gpu_search_fn(ctx, 10, 1, "protein")
+    a = ksd.search_queries_sharded(fn, q[0], q[1], t[0], t[1])
+    b = ksd.search_index_sharded(fn, q[0], q[1], t[0], t[1])
+    want = fn(q[0], q[1], t[0], t[1])
+    for x, y, z in zip(a, b, want):
+        assert np.array_equal(x, z) and np.array_equal(y, z)
