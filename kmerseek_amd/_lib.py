@@ -58,6 +58,7 @@ SIGNATURES = {
     "ks_last_error": (C.c_char_p, [_vp]),
     "ks_ctx_stream": (_vp, [_vp]),
     "ks_ctx_synchronize": (C.c_int, [_vp]),
+    "ks_ctx_pool_stats": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
     "ks_validate_and_resolve": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, C.c_uint64, C.c_char_p, _u64p,
                                           C.POINTER(ks_residue_error)]),
     "ks_sketch_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _parp, _pp]),

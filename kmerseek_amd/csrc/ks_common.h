@@ -40,13 +40,15 @@ struct ks_ctx {
     int n_cus = 256;
     std::string err;
     std::vector<ks_pool_block> pool;
+    u64 pool_mallocs = 0; // hipMalloc calls made by the pool (0 in steady state)
     // timing
-    bool timing = false;
+    int timing = 0; // 0 off, 1 every launch, 2 only the kernels that carry the bytes (lower event overhead)
     std::vector<std::string> t_names;
     std::vector<u64> t_launches;
     std::vector<double> t_ms;
     std::vector<ks_timer_slot> t_pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> t_free;
+    bool t_open = false; // the last ks_timer_begin recorded a start event
     // small pinned host scratch for counters read back from the device
     u64 *h_pin = nullptr; // 64 x u64
     // encode LUTs (3 x 256 bytes) in device memory

@@ -143,6 +143,18 @@ extern "C" int ks_ctx_synchronize(ks_ctx *ctx) {
     return KS_OK;
 }
 
+extern "C" int ks_ctx_pool_stats(const ks_ctx *ctx, uint64_t *n_blocks, uint64_t *bytes_held, uint64_t *bytes_in_use,
+                                 uint64_t *n_mallocs) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    u64 held = 0, used = 0;
+    for (auto &b : ctx->pool) { held += b.size; if (b.in_use) used += b.size; }
+    if (n_blocks) *n_blocks = ctx->pool.size();
+    if (bytes_held) *bytes_held = held;
+    if (bytes_in_use) *bytes_in_use = used;
+    if (n_mallocs) *n_mallocs = ctx->pool_mallocs;
+    return KS_OK;
+}
+
 // ---- pool ---------------------------------------------------------------------------------
 void *ks_pool_alloc(ks_ctx *ctx, size_t bytes) {
     if (bytes == 0) bytes = 256;
@@ -167,6 +179,7 @@ void *ks_pool_alloc(ks_ctx *ctx, size_t bytes) {
         return nullptr;
     }
     ctx->pool.push_back({p, want, true});
+    ctx->pool_mallocs++;
     return p;
 }
 
@@ -210,8 +223,19 @@ static void timer_resolve(ks_ctx *ctx) {
     ctx->t_pending.clear();
 }
 
+// the kernels that move the bulk of the bytes: the only ones bracketed in mode 2
+static bool timer_is_major(const char *name) {
+    static const char *const major[] = {"sketch_tiles", "radix_scatter.qpart", "radix_hist.qpart", "join_buckets",
+                                        "radix_scatter.index", "sketch_long", "sketch_medium"};
+    for (const char *m : major)
+        if (!strcmp(name, m)) return true;
+    return false;
+}
+
 void ks_timer_begin(ks_ctx *ctx, const char *name) {
+    ctx->t_open = false;
     if (!ctx->timing) return;
+    if (ctx->timing == 2 && !timer_is_major(name)) return;
     if (ctx->t_pending.size() >= 4096) timer_resolve(ctx);
     ks_timer_slot s;
     if (!ctx->t_free.empty()) {
@@ -224,17 +248,19 @@ void ks_timer_begin(ks_ctx *ctx, const char *name) {
     s.name_id = timer_name_id(ctx, name);
     (void)hipEventRecord(s.a, ctx->stream);
     ctx->t_pending.push_back(s);
+    ctx->t_open = true;
 }
 
 void ks_timer_end(ks_ctx *ctx) {
-    if (!ctx->timing || ctx->t_pending.empty()) return;
+    if (!ctx->t_open || ctx->t_pending.empty()) return;
     (void)hipEventRecord(ctx->t_pending.back().b, ctx->stream);
+    ctx->t_open = false;
 }
 
 extern "C" int ks_timing_enable(ks_ctx *ctx, int enable) {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!enable) timer_resolve(ctx);
-    ctx->timing = enable != 0;
+    ctx->timing = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
     return KS_OK;
 }
 

@@ -119,6 +119,11 @@ class Context:
     def synchronize(self):
         self._check(self._L.ks_ctx_synchronize(self._h))
 
+    def pool_stats(self) -> Dict[str, int]:
+        v = [C.c_uint64(0) for _ in range(4)]
+        self._check(self._L.ks_ctx_pool_stats(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("blocks", "bytes_held", "bytes_in_use", "mallocs"), (int(x.value) for x in v)))
+
     # ---- sketch ----
     def sketch_batch(self, residues: np.ndarray, offsets: np.ndarray, ksize: int, scaled: int, moltype: str,
                      seed: int = SEED) -> "Sketches":
@@ -178,8 +183,9 @@ class Context:
         return Hits(self, out)
 
     # ---- measurement ----
-    def timing_enable(self, on: bool = True):
-        self._check(self._L.ks_timing_enable(self._h, 1 if on else 0))
+    def timing_enable(self, on=True):
+        """on: False/0 off, True/1 every launch, 2 only the kernels that carry the bytes (low overhead)."""
+        self._check(self._L.ks_timing_enable(self._h, int(on)))
 
     def timing_reset(self):
         self._check(self._L.ks_timing_reset(self._h))

@@ -38,7 +38,8 @@ def child(args):
         return r
     for _ in range(2):
         r = step()
-    ctx.timing_reset(); ctx.timing_enable(True)
+    pool0 = ctx.pool_stats()
+    ctx.timing_reset(); ctx.timing_enable(not args.no_events)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -47,7 +48,8 @@ def child(args):
     el = (time.perf_counter() - t0) / args.steps * 1e3
     ctx.timing_enable(False)
     tm = {k_: round(v[1] / args.steps, 3) for k_, v in ctx.timing().items()}
-    out = {"variant": args.variant, "ms_per_step": round(el, 3), "stats": r, "kernels": tm}
+    out = {"variant": args.variant, "ms_per_step": round(el, 3), "stats": r, "kernels": tm, "pool_before": pool0,
+           "pool_after": ctx.pool_stats()}
     import ctypes
     L = ks._lib.load()
     if hasattr(L, "ks_debug_read_stamps"):
@@ -69,6 +71,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--cache", default="/tmp/ks_mb")
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--no-events", action="store_true")
     ap.add_argument("--variant", default="base")
     args = ap.parse_args()
     if args.child:
@@ -92,7 +95,7 @@ def main():
         env = dict(os.environ, KMERSEEK_AMD_LIB=so)
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--variant", v, "--cache", cache,
                "--ksize", str(args.ksize), "--scaled", str(args.scaled), "--moltype", args.moltype,
-               "--steps", str(args.steps)]
+               "--steps", str(args.steps)] + (["--no-events"] if args.no_events else [])
         subprocess.call(cmd, env=env, timeout=300)
         sys.stdout.flush()
 
