@@ -194,6 +194,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     // ---- phase 0: tile -> sequence range (planned ahead), zero LDS state, stage LUT + sequence boundaries
     __shared__ u32 tile_s;
     __shared__ u32 ext_n;
+    __shared__ u32 ext_n_heavy; // heavy-bucket queue cursor
     __shared__ u32 ext_seq[4], ext_cnt[4], ext_d[4];
     __shared__ unsigned long long base_s;
     u32 tile = blockIdx.x;
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     if (tid < 256) lut_s[tid] = A.lut[tid];
     for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
     if (tid < SK_NFLAG) flagbits[tid] = 0;
+    if (tid == 0) ext_n_heavy = 0;
     u64 span_end = A.offs[s_end];
     if (span_end > g0 + SK_TILE) span_end = g0 + SK_TILE;
     __syncthreads();
@@ -311,38 +313,81 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     // ---- phase 5: rank inside the bucket; first arrival of each distinct hash is its representative
     u32 pr[SK_E]; // (sorted position << 1) | is_representative, or ~0
     u32 ab[SK_E];
-    {
-        u32 sb[SK_E], c[SK_E], less[SK_E], eqb[SK_E];
-        u32 maxc = 0;
+    // Buckets hold ~1 element: 3 out of 4 kept hashes sit in a bucket of size 1 or 2 and are ranked with at most one
+    // LDS read.  The rest ("heavy": bucket of 3+) would make every wave iterate to ITS largest bucket in each of the
+    // 8 slots, so they are queued (in the unused tail of tmp) and ranked by all threads evenly in a second pass.
+    const u32 n_kept = bstart(SK_TILE);
+    u32 *queue = (u32 *)(tmp + n_kept);
+    const u32 qcap = (SK_TILE - n_kept) * 2;
+    u32 eidx[SK_E / 2]; // queue slot of a heavy element, 16 bits per slot (0xffff = none)
 #pragma unroll
-        for (int i = 0; i < SK_E; i++) {
-            sb[i] = 0; c[i] = 0; less[i] = 0; eqb[i] = 0; ab[i] = 0;
-            if (bo[i] != 0xffffffffu) {
-                const u32 b = bo[i] >> 16;
-                sb[i] = bstart(b);
-                c[i] = bstart(b + 1) - sb[i];
-            }
-            maxc = c[i] > maxc ? c[i] : maxc;
+    for (int i = 0; i < SK_E / 2; i++) eidx[i] = 0xffffffffu;
+    auto rank_in_bucket = [&](u32 sb, u32 c, u32 o, u64 hh, u32 &p, u32 &eq, u32 &rep) {
+        u32 less = 0, eqb = 0;
+        eq = 0;
+        for (u32 j = 0; j < c; j++) {
+            const u64 x = tmp[sb + j];
+            less += x < hh;
+            eq += x == hh;
+            eqb += (x == hh) & (j < o);
         }
-        for (u32 j = 0; j < maxc; j++) {
+        p = sb + less + eqb;
+        rep = eqb == 0;
+    };
 #pragma unroll
-            for (int i = 0; i < SK_E; i++) {
-                if (j < c[i]) {
-                    const u64 x = tmp[sb[i] + j];
-                    less[i] += x < h[i];
-                    ab[i] += x == h[i];
-                    eqb[i] += (x == h[i]) & (j < (bo[i] & 0xffffu));
+    for (int i = 0; i < SK_E; i++) {
+        pr[i] = 0xffffffffu;
+        ab[i] = 0;
+        if (bo[i] != 0xffffffffu) {
+            const u32 b = bo[i] >> 16, o = bo[i] & 0xffffu;
+            const u32 sb = bstart(b), c = bstart(b + 1) - sb;
+            u32 p = sb, eq = 1, rep = 1;
+            bool done = true;
+            if (c == 2) {
+                const u64 x = tmp[sb + (o ^ 1u)];
+                const u32 same = x == h[i];
+                p = sb + (x < h[i]) + (same & (o == 1u));
+                eq = 1 + same;
+                rep = !(same & (o == 1u));
+            } else if (c > 2) {
+                const u32 e = atomicAdd(&ext_n_heavy, 1u);
+                if (e < qcap && e < 0xffffu) {
+                    queue[e] = b | (o << 12);
+                    eidx[i >> 1] = (eidx[i >> 1] & ~(0xffffu << ((i & 1) * 16))) | (e << ((i & 1) * 16));
+                    done = false;
+                } else {
+                    rank_in_bucket(sb, c, o, h[i], p, eq, rep); // no queue room (tile nearly full): rank in place
                 }
             }
-        }
-#pragma unroll
-        for (int i = 0; i < SK_E; i++) {
-            pr[i] = 0xffffffffu;
-            if (bo[i] != 0xffffffffu) {
-                const u32 p = sb[i] + less[i] + eqb[i];
-                pr[i] = (p << 1) | (eqb[i] == 0);
-                if (eqb[i] == 0) atomicOr(&flagbits[p >> 5], 1u << (p & 31));
+            if (done) {
+                pr[i] = (p << 1) | rep;
+                ab[i] = eq;
+                if (rep) atomicOr(&flagbits[p >> 5], 1u << (p & 31));
             }
+        }
+    }
+    __syncthreads();
+    {
+        u32 nq = ext_n_heavy;
+        if (nq > qcap) nq = qcap;
+        if (nq > 0xffffu) nq = 0xffffu;
+        for (u32 e = tid; e < nq; e += SK_THREADS) {
+            const u32 code = queue[e], b = code & 0xfffu, o = code >> 12;
+            const u32 sb = bstart(b), c = bstart(b + 1) - sb;
+            u32 p, eq, rep;
+            rank_in_bucket(sb, c, o, tmp[sb + o], p, eq, rep);
+            queue[e] = p | (rep << 12) | (eq << 13);
+            if (rep) atomicOr(&flagbits[p >> 5], 1u << (p & 31));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SK_E; i++) {
+        const u32 e = (eidx[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+        if (e != 0xffffu) {
+            const u32 r = queue[e];
+            pr[i] = ((r & 0xfffu) << 1) | ((r >> 12) & 1u);
+            ab[i] = r >> 13;
         }
     }
     __syncthreads();
