@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; collected separately as the MI355X guide prescribes)
+into profiles/traffic.json: HBM bytes per launch of the byte-moving kernels.
+
+gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports exactly half the bytes of a wide coalesced read, so it
+is doubled; WRITE_SIZE is exact.  Both counters are in KiB.
+
+    python tools/pmc_to_traffic.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+NAMES = {  # profiler kernel name prefix -> library timing name
+    "void k_sketch_tiles<0>": "sketch_tiles",
+    "void k_radix_scatter<unsigned int, 1>": "radix_scatter.qpart",
+    "void k_radix_hist<1>": "radix_hist.qpart",
+    "k_join_buckets": "join_buckets",
+    "void k_radix_scatter<unsigned long, 0>": "radix_scatter.index",
+}
+
+
+def load(path, counter):
+    out = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            out[r["Kernel_Name"]].append((float(r["Counter_Value"]), int(r["Grid_Size"])))
+    return out
+
+
+def main():
+    f = load(sys.argv[1], "FETCH_SIZE")
+    w = load(sys.argv[2], "WRITE_SIZE")
+    res = {}
+    for kname, rows in f.items():
+        for pref, lib in NAMES.items():
+            if kname.startswith(pref):
+                g = max(x[1] for x in rows)  # the full-size launches (largest grid)
+                fetch = [x[0] for x in rows if x[1] == g]
+                write = [x[0] for x in w.get(kname, []) if x[1] == g]
+                fb = 2.0 * 1024.0 * sum(fetch) / len(fetch)
+                wb = 1024.0 * sum(write) / max(len(write), 1)
+                res[lib] = {"fetch_bytes": fb, "write_bytes": wb, "launches_sampled": len(fetch)}
+    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 0`",
+           "correction": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), WRITE_SIZE exact; KiB -> bytes",
+           "per_launch_bytes": {k: v["fetch_bytes"] + v["write_bytes"] for k, v in res.items()},
+           "detail": res}
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out["per_launch_bytes"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
