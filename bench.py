@@ -123,8 +123,9 @@ def main():
     n_t_postings = index.n_postings
 
     def step():
-        Q = ctx.sketch_batch_device(q_res.data_ptr(), q_off.data_ptr(), args.queries, len(q_res_h), k, scaled, mol,
-                                    max_seq_len=q_maxlen)
+        # sketch for an immediate search: the sketch kernel also writes the postings pre-partitioned for the join
+        Q = ctx.sketch_queries_device(index, q_res.data_ptr(), q_off.data_ptr(), args.queries, len(q_res_h),
+                                      max_seq_len=q_maxlen)
         H = ctx.search(index, Q)
         out = (Q.n_hashes, H.count, H.n_pair_instances)
         H.free()

@@ -92,6 +92,13 @@ int ks_ctx_synchronize(ks_ctx *ctx);
 int ks_ctx_pool_stats(const ks_ctx *ctx, uint64_t *n_blocks, uint64_t *bytes_held, uint64_t *bytes_in_use,
                       uint64_t *n_mallocs);
 
+/* Plain device buffers for callers that have no HIP binding of their own (the *_device entry points take raw
+ * device pointers): 256-byte aligned allocations on ctx's device, stream-ordered copies that return when done. */
+int ks_dev_malloc(ks_ctx *ctx, uint64_t bytes, void **out);
+int ks_dev_free(ks_ctx *ctx, void *ptr);
+int ks_dev_upload(ks_ctx *ctx, void *dst_device, const void *src_host, uint64_t bytes);
+int ks_dev_download(ks_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
+
 /* ---- host-side pre-step ------------------------------------------------------------------ */
 
 typedef struct ks_residue_error {
@@ -131,9 +138,19 @@ int ks_sketch_batch_device(ks_ctx *ctx, const uint8_t *d_residues, const uint64_
                            uint32_t n_seqs, uint64_t n_residues, uint32_t max_seq_len,
                            const ks_params *params, ks_sketches **out);
 
+/* Sketch a QUERY batch that is about to be searched against `index` (sketch parameters are the index's).  Same result
+ * as ks_sketch_batch_device; in addition the sketch kernel writes the batch's postings already partitioned on the hash
+ * bits the join against this index consumes, so the following ks_search skips its first partition pass (the sketch
+ * kernel is ALU-bound: the extra writes ride on idle memory pipes).  If the hashes are too skewed for the fixed-size
+ * regions the postings are dropped and ks_search partitions as usual — results are identical either way. */
+int ks_sketch_queries_device(ks_ctx *ctx, const ks_index *index, const uint8_t *d_residues,
+                             const uint64_t *d_seq_offsets, uint32_t n_seqs, uint64_t n_residues,
+                             uint32_t max_seq_len, ks_sketches **out);
+
 uint32_t ks_sketches_n_seqs(const ks_sketches *s);
 uint64_t ks_sketches_n_hashes(const ks_sketches *s);
 uint64_t ks_sketches_n_windows(const ks_sketches *s); /* k-mer windows hashed to build it */
+int ks_sketches_has_postings(const ks_sketches *s);   /* 1 if ks_sketch_queries_device's partitioned postings are attached */
 void ks_sketches_params(const ks_sketches *s, ks_params *out);
 /* device pointers (valid until ks_sketches_free): offsets u64[n+1], hashes u64[], abund u32[] */
 const uint64_t *ks_sketches_device_offsets(const ks_sketches *s);

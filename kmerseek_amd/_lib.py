@@ -58,11 +58,17 @@ SIGNATURES = {
     "ks_last_error": (C.c_char_p, [_vp]),
     "ks_ctx_stream": (_vp, [_vp]),
     "ks_ctx_synchronize": (C.c_int, [_vp]),
+    "ks_dev_malloc": (C.c_int, [_vp, C.c_uint64, _pp]),
+    "ks_dev_free": (C.c_int, [_vp, _vp]),
+    "ks_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
+    "ks_dev_download": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "ks_ctx_pool_stats": (C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
     "ks_validate_and_resolve": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int, C.c_uint64, C.c_char_p, _u64p,
                                           C.POINTER(ks_residue_error)]),
     "ks_sketch_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _parp, _pp]),
     "ks_sketch_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32, _parp, _pp]),
+    "ks_sketch_queries_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32, _pp]),
+    "ks_sketches_has_postings": (C.c_int, [_vp]),
     "ks_sketches_n_seqs": (C.c_uint32, [_vp]),
     "ks_sketches_n_hashes": (C.c_uint64, [_vp]),
     "ks_sketches_n_windows": (C.c_uint64, [_vp]),

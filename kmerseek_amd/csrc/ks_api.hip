@@ -10,7 +10,16 @@ extern "C" int ks_sketch_batch_device(ks_ctx *ctx, const uint8_t *d_residues, co
                                       const ks_params *params, ks_sketches **out) {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
-    return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, params, out);
+    return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, params, 0, out);
+}
+
+extern "C" int ks_sketch_queries_device(ks_ctx *ctx, const ks_index *index, const uint8_t *d_residues,
+                                        const uint64_t *d_seq_offsets, uint32_t n_seqs, uint64_t n_residues,
+                                        uint32_t max_seq_len, ks_sketches **out) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (!index || !out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, &index->params,
+                                 ks_join_pbits(index->n_postings), out);
 }
 
 static int upload_batch(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_offsets, uint32_t n_seqs,
@@ -46,7 +55,7 @@ extern "C" int ks_sketch_batch(ks_ctx *ctx, const uint8_t *residues, const uint6
     u64 n_res = 0;
     u32 max_len = 0;
     int st = upload_batch(ctx, residues, seq_offsets, n_seqs, &d_res, &d_offs, &n_res, &max_len);
-    if (st == KS_OK) st = ks_sketch_device_impl(ctx, d_res, d_offs, n_seqs, n_res, max_len, params, out);
+    if (st == KS_OK) st = ks_sketch_device_impl(ctx, d_res, d_offs, n_seqs, n_res, max_len, params, 0, out);
     (void)hipStreamSynchronize(ctx->stream);
     ks_pool_free(ctx, d_res);
     ks_pool_free(ctx, d_offs);
@@ -56,6 +65,7 @@ extern "C" int ks_sketch_batch(ks_ctx *ctx, const uint8_t *residues, const uint6
 extern "C" uint32_t ks_sketches_n_seqs(const ks_sketches *s) { return s ? s->n_seqs : 0; }
 extern "C" uint64_t ks_sketches_n_hashes(const ks_sketches *s) { return s ? s->n_hashes : 0; }
 extern "C" uint64_t ks_sketches_n_windows(const ks_sketches *s) { return s ? s->n_windows : 0; }
+extern "C" int ks_sketches_has_postings(const ks_sketches *s) { return (s && s->part_keys) ? 1 : 0; }
 extern "C" void ks_sketches_params(const ks_sketches *s, ks_params *out) { if (s && out) *out = s->params; }
 extern "C" const uint64_t *ks_sketches_device_offsets(const ks_sketches *s) { return s ? s->d_offsets : nullptr; }
 extern "C" const uint64_t *ks_sketches_device_hashes(const ks_sketches *s) { return s ? s->d_hashes : nullptr; }
@@ -112,6 +122,9 @@ extern "C" void ks_sketches_free(ks_sketches *s) {
     ks_pool_free(s->ctx, s->d_offsets);
     ks_pool_free(s->ctx, s->d_hashes);
     ks_pool_free(s->ctx, s->d_abunds);
+    ks_pool_free(s->ctx, s->part_keys);
+    ks_pool_free(s->ctx, s->part_vals);
+    ks_pool_free(s->ctx, s->part_len);
     delete s;
 }
 

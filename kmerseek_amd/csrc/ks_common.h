@@ -106,6 +106,15 @@ struct ks_sketches {
     u64 *d_offsets; // n_seqs + 1
     u64 *d_hashes;  // n_hashes
     u32 *d_abunds;  // n_hashes
+    // optional, made by ks_sketch_queries_device: postings (hash, seq) already partitioned on hash bits
+    // [part_shift, part_shift + 8) into part_regions fixed-capacity regions (region r holds part_len[r] records
+    // starting at r * part_cap) — the first partition pass of a search against an index that joins on part_pbits bits
+    u64 *part_keys;
+    u32 *part_vals;
+    u32 *part_len;  // device, [part_regions]
+    u64 part_cap;
+    u32 part_regions;
+    int part_pbits, part_shift;
 };
 
 struct ks_index {
@@ -144,14 +153,24 @@ int ks_scan_u32_inplace(ks_ctx *ctx, u32 *data, u64 n, u32 *d_total);
 // passes ping-pong between the scratch pairs (ka, va) and (kb, vb); *keys_out / *vals_out point at the
 // result.  `tag` picks the kernel instantiation name ("radix_scatter.<tag>" in the timing table).
 enum { KS_SORT_INDEX = 0, KS_SORT_QPART = 1, KS_SORT_PAIRS = 2 };
+// optional segmented input of the FIRST pass: `regions` fixed-capacity regions, region r = len[r] records at r * cap
+struct ks_rs_segments {
+    const u32 *len; // device
+    u64 cap;
+    u32 regions;
+};
 int ks_radix_sort_u32(ks_ctx *ctx, int tag, const u64 *keys_in, const u32 *vals_in, u64 *ka, u32 *va, u64 *kb, u32 *vb,
-                      u64 n, const int *shifts, int n_shifts, u64 **keys_out, u32 **vals_out);
+                      u64 n, const int *shifts, int n_shifts, u64 **keys_out, u32 **vals_out,
+                      const ks_rs_segments *seg = nullptr);
 int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_in, u64 *ka, u64 *va, u64 *kb, u64 *vb,
                       u64 n, const int *shifts, int n_shifts, u64 **keys_out, u64 **vals_out);
 
 // ---- pipelines (ks_sketch.hip, ks_search.hip) ----
+// part_pbits > 0: also emit postings partitioned for a join on the top part_pbits hash bits
 int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,
-                          u32 max_seq_len, const ks_params *p, ks_sketches **out);
+                          u32 max_seq_len, const ks_params *p, int part_pbits, ks_sketches **out);
+// bits of hash prefix the join against an index of n_postings uses (buckets of ~3k index postings, <= 16)
+int ks_join_pbits(u64 n_postings);
 int ks_kmerpos_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,
                            const ks_params *p, ks_kmerpos **out);
 int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out);

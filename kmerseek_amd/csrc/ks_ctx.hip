@@ -155,6 +155,31 @@ extern "C" int ks_ctx_pool_stats(const ks_ctx *ctx, uint64_t *n_blocks, uint64_t
     return KS_OK;
 }
 
+extern "C" int ks_dev_malloc(ks_ctx *ctx, uint64_t bytes, void **out) {
+    if (!ctx || !out) return KS_ERR_INVALID_ARG;
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    if (hipMalloc(out, bytes ? bytes : 256) != hipSuccess) { (void)hipGetLastError(); return ks_fail(ctx, KS_ERR_OOM, "hipMalloc(%llu) failed", (unsigned long long)bytes); }
+    return KS_OK;
+}
+extern "C" int ks_dev_free(ks_ctx *ctx, void *ptr) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KS_HIP(ctx, hipFree(ptr));
+    return KS_OK;
+}
+extern "C" int ks_dev_upload(ks_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return KS_ERR_INVALID_ARG;
+    if (bytes) KS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KS_OK;
+}
+extern "C" int ks_dev_download(ks_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return KS_ERR_INVALID_ARG;
+    if (bytes) KS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KS_OK;
+}
+
 // ---- pool ---------------------------------------------------------------------------------
 void *ks_pool_alloc(ks_ctx *ctx, size_t bytes) {
     if (bytes == 0) bytes = 256;

@@ -159,19 +159,38 @@ int ks_scan_u32_inplace(ks_ctx *ctx, u32 *data, u64 n, u32 *d_total) {
 #define RS_TILE (RS_THREADS * RS_IPT) // 8192 records: ~32 per digit, so digits leave the tile as >= 128-B runs
 #define RS_WAVES (RS_THREADS / 64)
 
+// Input geometry of a pass.  Dense: tile b covers records [b*RS_TILE, ...) of n.  Segmented (seg_len != NULL): the
+// input is a set of fixed-capacity regions (region r holds seg_len[r] records from r*seg_cap on) and tile b is the
+// (b % tiles_per_seg)-th tile of region b / tiles_per_seg — how the sketch kernel's pre-partitioned postings enter.
+KS_DEV void rs_tile_geom(u64 n, const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg, u64 &in_base, u32 &nvalid) {
+    if (seg_len) {
+        const u32 r = blockIdx.x / tiles_per_seg, j = blockIdx.x % tiles_per_seg;
+        const u64 len = seg_len[r], off = (u64)j * RS_TILE;
+        nvalid = off < len ? (u32)((len - off) < RS_TILE ? (len - off) : RS_TILE) : 0u;
+        in_base = (u64)r * seg_cap + off;
+    } else {
+        in_base = (u64)blockIdx.x * RS_TILE;
+        const u64 remain = n - in_base;
+        nvalid = remain < RS_TILE ? (u32)remain : RS_TILE;
+    }
+}
+
 // TAG only gives the instantiations of one kernel distinct names per use (index build / query
 // partition / match sort), so profiler rows and the library's own HIP-event table line up.
 // hist[d * nblocks + block] = number of keys of this block's tile with digit d
 template <int TAG>
-__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 *hist, u64 n, int shift, u32 nblocks) {
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 *hist, u64 n, int shift, u32 nblocks,
+                                                           const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg) {
     __shared__ u32 bins[256];
     if (threadIdx.x < 256) bins[threadIdx.x] = 0;
     __syncthreads();
-    const u64 base = (u64)blockIdx.x * RS_TILE;
+    u64 base;
+    u32 nvalid;
+    rs_tile_geom(n, seg_len, seg_cap, tiles_per_seg, base, nvalid);
 #pragma unroll
     for (int i = 0; i < RS_IPT; i++) {
-        u64 idx = base + (u64)i * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&bins[(u32)(keys[idx] >> shift) & 255u], 1u);
+        const u32 li = (u32)i * RS_THREADS + threadIdx.x;
+        if (li < nvalid) atomicAdd(&bins[(u32)(keys[base + li] >> shift) & 255u], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 256) hist[(u64)threadIdx.x * nblocks + blockIdx.x] = bins[threadIdx.x];
@@ -183,7 +202,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 
 // digit leaves the tile as a contiguous run of full cache lines.
 template <typename V, int TAG>
 __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64 *kin, const V *vin, u64 *kout, V *vout,
-                                                              const u32 *goffs, u64 n, int shift, u32 nblocks) {
+                                                              const u32 *goffs, u64 n, int shift, u32 nblocks,
+                                                              const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg) {
     __shared__ u32 wcnt[RS_WAVES][256];
     __shared__ u32 dstart[256];
     __shared__ u32 gbase[256];
@@ -197,22 +217,24 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
     }
     __syncthreads();
 
-    const u64 tile_base = (u64)blockIdx.x * RS_TILE;
-    const u64 wbase = tile_base + (u64)wave * (64 * RS_IPT);
+    u64 tile_base;
+    u32 nvalid;
+    rs_tile_geom(n, seg_len, seg_cap, tiles_per_seg, tile_base, nvalid);
+    const u32 wloc = wave * (64 * RS_IPT); // this wave's first record inside the tile
     u64 key[RS_IPT];
     V val[RS_IPT];
     u32 rank[RS_IPT]; // (digit << 16) | rank within (wave, digit)
 #pragma unroll
     for (int r = 0; r < RS_IPT; r++) {
-        u64 idx = wbase + (u64)r * 64 + lane;
-        bool valid = idx < n;
-        key[r] = valid ? kin[idx] : ~0ULL;
-        val[r] = valid ? vin[idx] : (V)0;
+        const u32 li = wloc + (u32)r * 64 + lane;
+        const bool valid = li < nvalid;
+        key[r] = valid ? kin[tile_base + li] : ~0ULL;
+        val[r] = valid ? vin[tile_base + li] : (V)0;
     }
 #pragma unroll
     for (int r = 0; r < RS_IPT; r++) {
-        u64 idx = wbase + (u64)r * 64 + lane;
-        u32 d = idx < n ? ((u32)(key[r] >> shift) & 255u) : 255u;
+        const u32 li = wloc + (u32)r * 64 + lane;
+        u32 d = li < nvalid ? ((u32)(key[r] >> shift) & 255u) : 255u;
         // lanes holding the same digit
         u64 peers = ~0ULL;
 #pragma unroll
@@ -253,8 +275,6 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
         stage[pos[r]] = key[r];
     }
     __syncthreads();
-    const u64 remain = n - tile_base;
-    const u32 nvalid = remain < RS_TILE ? (u32)remain : RS_TILE;
     u32 gdst[RS_IPT]; // global destination of local slot i*RS_THREADS + tid
 #pragma unroll
     for (int i = 0; i < RS_IPT; i++) {
@@ -283,14 +303,16 @@ static const char *const rs_tag_names[3] = {"index", "qpart", "pairs"};
 
 template <typename V, int TAG>
 static int radix_sort_tagged(ks_ctx *ctx, const u64 *keys_in, const V *vals_in, u64 *ka, V *va, u64 *kb, V *vb, u64 n,
-                             const int *shifts, int n_shifts, u64 **keys_out, V **vals_out) {
+                             const int *shifts, int n_shifts, u64 **keys_out, V **vals_out, const ks_rs_segments *seg) {
     *keys_out = (u64 *)keys_in;
     *vals_out = (V *)vals_in;
     if (n <= 1 || n_shifts <= 0) return KS_OK;
     if (n >= 0xffffffffULL) return ks_fail(ctx, KS_ERR_CAPACITY, "radix sort: %llu records exceed the 32-bit offset range", (unsigned long long)n);
-    const u32 nblocks = (u32)((n + RS_TILE - 1) / RS_TILE);
+    const u32 nblocks_dense = (u32)((n + RS_TILE - 1) / RS_TILE);
+    const u32 tiles_per_seg = seg ? (u32)((seg->cap + RS_TILE - 1) / RS_TILE) : 0;
+    const u32 nblocks_seg = seg ? seg->regions * tiles_per_seg : 0;
     u32 *hist = nullptr;
-    KS_TRY(ks_alloc(ctx, &hist, (size_t)256 * nblocks));
+    KS_TRY(ks_alloc(ctx, &hist, (size_t)256 * (nblocks_seg > nblocks_dense ? nblocks_seg : nblocks_dense)));
     const std::string nm_hist = std::string("radix_hist.") + rs_tag_names[TAG], nm_scat = std::string("radix_scatter.") + rs_tag_names[TAG];
     const u64 *kin = keys_in;
     const V *vin = vals_in;
@@ -300,14 +322,20 @@ static int radix_sort_tagged(ks_ctx *ctx, const u64 *keys_in, const V *vals_in, 
     for (int i = 0; i < n_shifts && st == KS_OK; i++) {
         u64 *kout = to_a ? ka : kb;
         V *vout = to_a ? va : vb;
+        // only the first pass can read a segmented input; its output (and every later pass) is dense
+        const bool segmented = seg && i == 0;
+        const u32 nblocks = segmented ? nblocks_seg : nblocks_dense;
+        const u32 *s_len = segmented ? seg->len : nullptr;
+        const u64 s_cap = segmented ? seg->cap : 0;
         ks_timer_begin(ctx, nm_hist.c_str());
-        hipLaunchKernelGGL((k_radix_hist<TAG>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, kin, hist, n, shifts[i], nblocks);
+        hipLaunchKernelGGL((k_radix_hist<TAG>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, kin, hist, n, shifts[i], nblocks,
+                           s_len, s_cap, tiles_per_seg);
         ks_timer_end(ctx);
         st = ks_scan_u32_inplace(ctx, hist, (u64)256 * nblocks, nullptr);
         if (st != KS_OK) break;
         ks_timer_begin(ctx, nm_scat.c_str());
         hipLaunchKernelGGL((k_radix_scatter<V, TAG>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, kin, vin, kout, vout,
-                           (const u32 *)hist, n, shifts[i], nblocks);
+                           (const u32 *)hist, n, shifts[i], nblocks, s_len, s_cap, tiles_per_seg);
         ks_timer_end(ctx);
         if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "radix sort launch failed");
         kin = kout;
@@ -321,13 +349,13 @@ static int radix_sort_tagged(ks_ctx *ctx, const u64 *keys_in, const V *vals_in, 
 }
 
 int ks_radix_sort_u32(ks_ctx *ctx, int tag, const u64 *keys_in, const u32 *vals_in, u64 *ka, u32 *va, u64 *kb, u32 *vb, u64 n,
-                      const int *shifts, int n_shifts, u64 **keys_out, u32 **vals_out) {
+                      const int *shifts, int n_shifts, u64 **keys_out, u32 **vals_out, const ks_rs_segments *seg) {
     if (tag == KS_SORT_QPART)
-        return radix_sort_tagged<u32, KS_SORT_QPART>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out);
-    return radix_sort_tagged<u32, KS_SORT_PAIRS>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out);
+        return radix_sort_tagged<u32, KS_SORT_QPART>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out, seg);
+    return radix_sort_tagged<u32, KS_SORT_PAIRS>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out, seg);
 }
 int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_in, u64 *ka, u64 *va, u64 *kb, u64 *vb, u64 n,
                       const int *shifts, int n_shifts, u64 **keys_out, u64 **vals_out) {
     (void)tag;
-    return radix_sort_tagged<u64, KS_SORT_INDEX>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out);
+    return radix_sort_tagged<u64, KS_SORT_INDEX>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out, nullptr);
 }

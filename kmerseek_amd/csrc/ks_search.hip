@@ -110,6 +110,20 @@ done:
 #endif
 //                          index keys staged per chunk: 48 KiB of LDS -> 3 workgroups (24 waves) per CU
 
+int ks_join_pbits(u64 n_postings) { // buckets of ~3k index postings; the query side is partitioned on the same bits
+    int pbits = 0;
+    while (pbits < 16 && (n_postings >> pbits) > 3072) pbits++;
+    return pbits;
+}
+
+// query-side bucket bounds when the sketch kernel's regions ARE the buckets (pbits <= 8): no partition pass at all
+__global__ __launch_bounds__(256) void k_region_dir(const u32 *len, u64 cap, u32 n_regions, u64 *lo, u64 *hi) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_regions) return;
+    lo[b] = (u64)b * cap;
+    hi[b] = (u64)b * cap + len[b];
+}
+
 // dir[b] = first posting whose top `pbits` bits are >= b, for b in [0, 2^pbits]; keys are ordered on those bits
 __global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int pbits, u64 *dir) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -144,14 +158,14 @@ KS_DEV u32 jn_lower_bound_lds(const u64 *lk, u32 n, u64 h) {
 // Per round of JN_THREADS*JN_E query postings: search once, keep (position, run length) in registers,
 // reserve the round's slice of the pair list with ONE device-wide atomic, then write from registers.
 __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, const u32 *qids, const u64 *ikeys,
-                                                             const u32 *itids, const u32 *iabunds, const u64 *dir_q,
-                                                             const u64 *dir_t, u64 *pair_keys, u32 *pair_vals, u64 cap,
-                                                             unsigned long long *cursor) {
+                                                             const u32 *itids, const u32 *iabunds, const u64 *q_lo,
+                                                             const u64 *q_hi, const u64 *dir_t, u64 *pair_keys,
+                                                             u32 *pair_vals, u64 cap, unsigned long long *cursor) {
     __shared__ u64 lk[JN_CAP];
     __shared__ u32 scan_smem[JN_THREADS / 64 + 1];
     __shared__ unsigned long long base_s;
     const u32 tid = threadIdx.x;
-    const u64 qs = dir_q[blockIdx.x], qe = dir_q[blockIdx.x + 1];
+    const u64 qs = q_lo[blockIdx.x], qe = q_hi[blockIdx.x]; // dense postings: q_hi = q_lo + 1 (a directory)
     const u64 ts = dir_t[blockIdx.x], te = dir_t[blockIdx.x + 1];
     if (qs == qe || ts == te) return;
     for (u64 c0 = ts; c0 < te; c0 += JN_CAP) {
@@ -267,30 +281,49 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         return KS_OK;
     }
     {
-        // query postings
-        SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qk1, (size_t)n_q));
-        SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qv1, (size_t)n_q));
-        ks_timer_begin(ctx, "fill_query_vals");
-        hipLaunchKernelGGL(k_fill_query_vals, dim3((q->n_seqs + 3) / 4), dim3(256), 0, ctx->stream, (const u64 *)q->d_offsets, q->n_seqs, qv0);
-        ks_timer_end(ctx);
-        SE_HIP(hipGetLastError());
+        // ---- query postings grouped on the top pbits hash bits (the join needs locality, not order)
+        const int pbits = ks_join_pbits(n_t);
+        const u32 n_buckets = 1u << pbits;
         u64 *qk = nullptr;
         u32 *qv = nullptr;
-        // buckets of ~3k index postings; the query side is partitioned (not sorted) on the same top bits
-        int pbits = 0;
-        while (pbits < 16 && (n_t >> pbits) > 3072) pbits++;
-        {
-            // hashes are read straight from the query sketches on the first pass (no staging copy);
-            // qv0 holds the input qids, so the first pass lands in (qk1, qv1)
-            int shifts[2], ns = 0;
-            for (int sh = 64 - pbits; sh < 64; sh += 8) shifts[ns++] = sh;
-            SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_QPART, q->d_hashes, qv0, qk1, qv1, qk0, qv0, n_q, shifts, ns, &qk, &qv));
-        }
-        const u32 n_buckets = 1u << pbits;
-        SE_CHECK(ks_alloc(ctx, &dir_q, (size_t)n_buckets + 1));
+        const u64 *q_lo = nullptr, *q_hi = nullptr;
+        SE_CHECK(ks_alloc(ctx, &dir_q, (size_t)2 * n_buckets + 2));
         SE_CHECK(ks_alloc(ctx, &dir_t, (size_t)n_buckets + 1));
+        const bool pre = q->part_keys && q->part_pbits == pbits && pbits > 0;
+        if (pre && pbits <= 8) {
+            // the sketch kernel already wrote one region per bucket
+            qk = q->part_keys; qv = q->part_vals;
+            ks_timer_begin(ctx, "bucket_dir");
+            hipLaunchKernelGGL(k_region_dir, dim3((n_buckets + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)q->part_len,
+                               q->part_cap, n_buckets, dir_q, dir_q + n_buckets);
+            ks_timer_end(ctx);
+            q_lo = dir_q; q_hi = dir_q + n_buckets;
+        } else {
+            SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qk1, (size_t)n_q));
+            SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qv1, (size_t)n_q));
+            if (pre) {
+                // the sketch kernel did the low digit; one segmented pass on the remaining high bits finishes the job
+                const int shifts[1] = {64 - pbits + 8};
+                ks_rs_segments seg{q->part_len, q->part_cap, q->part_regions};
+                SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_QPART, q->part_keys, q->part_vals, qk1, qv1, qk0, qv0, n_q, shifts, 1,
+                                           &qk, &qv, &seg));
+            } else {
+                ks_timer_begin(ctx, "fill_query_vals");
+                hipLaunchKernelGGL(k_fill_query_vals, dim3((q->n_seqs + 3) / 4), dim3(256), 0, ctx->stream, (const u64 *)q->d_offsets, q->n_seqs, qv0);
+                ks_timer_end(ctx);
+                SE_HIP(hipGetLastError());
+                // hashes are read straight from the query sketches on the first pass (no staging copy);
+                // qv0 holds the input qids, so the first pass lands in (qk1, qv1)
+                int shifts[2], ns = 0;
+                for (int sh = 64 - pbits; sh < 64; sh += 8) shifts[ns++] = sh;
+                SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_QPART, q->d_hashes, qv0, qk1, qv1, qk0, qv0, n_q, shifts, ns, &qk, &qv));
+            }
+            ks_timer_begin(ctx, "bucket_dir");
+            hipLaunchKernelGGL(k_bucket_dir, dim3((n_buckets + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)qk, n_q, pbits, dir_q);
+            ks_timer_end(ctx);
+            q_lo = dir_q; q_hi = dir_q + 1;
+        }
         ks_timer_begin(ctx, "bucket_dir");
-        hipLaunchKernelGGL(k_bucket_dir, dim3((n_buckets + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)qk, n_q, pbits, dir_q);
         hipLaunchKernelGGL(k_bucket_dir, dim3((n_buckets + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys, n_t, pbits, dir_t);
         ks_timer_end(ctx);
         SE_HIP(hipGetLastError());
@@ -305,7 +338,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
             ks_timer_begin(ctx, "join_buckets");
             hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
                                (const u32 *)qv, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds,
-                               (const u64 *)dir_q, (const u64 *)dir_t, pk0, pv0, cap, cursor);
+                               q_lo, q_hi, (const u64 *)dir_t, pk0, pv0, cap, cursor);
             ks_timer_end(ctx);
             SE_HIP(hipGetLastError());
             SE_HIP(hipMemcpyAsync(ctx->h_pin, cursor, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));

@@ -72,8 +72,15 @@ struct sk_args {
     u32 *counts;    // [n_seqs] unique hashes of medium / long sequences (written by MODE 1 / k_sketch_long, read by MODE 0)
     // decoupled look-back across tiles (MODE 0)
     unsigned long long *tile_status; // [n_tiles] (flag << 62) | value; flag 1 = tile aggregate, 2 = inclusive prefix
-    u32 *ticket;    // [0] dynamic tile id, [1] error flag (a bounded spin expired)
+    u32 *ticket;    // [0] dynamic tile id, [1] status bits: 1 = a bounded spin expired, 2 = postings not emitted for some tile
     u32 n_tiles;
+    // optional: postings (hash, sequence) partitioned on hash bits [part_shift, part_shift + 8) into 256 fixed-capacity
+    // regions, written while the vector ALU is the bottleneck — the query side's first partition pass of ks_search
+    u64 *part_keys;   // [256 * part_cap] or NULL
+    u32 *part_vals;
+    u32 *part_cursor; // [256] records placed per region so far
+    u64 part_cap;
+    u32 part_shift, part_mask;
 };
 
 #define SK_FLAG_AGG (1ULL << 62)
@@ -115,7 +122,11 @@ KS_DEV u64 sk_hash_window(const u64 *w /* LDS words starting at pos8 */, u32 k, 
     return m.finish((u64)k);
 }
 
-#define SK_SEQ_CAP 510 // sequence boundaries of a tile staged in LDS (tiles with more fall back to global reads)
+#define SK_SEQ_CAP 254 // sequence boundaries of a tile staged in LDS (tiles with more fall back to global reads)
+// per-element code: sequence (relative to the tile's first, 8 bits) | bucket (12 bits) | arrival slot (12 bits)
+#define SK_BO_B(x) (((x) >> 12) & 0xfffu)
+#define SK_BO_O(x) ((x) & 0xfffu)
+#define SK_BO_S(x) ((x) >> 24)
 
 // Sequence boundaries of the tile in LOCAL coordinates (byte position relative to g0, clamped to 2^31-1),
 // served from LDS when the tile has <= SK_SEQ_CAP sequences, else straight from the offsets array.
@@ -159,7 +170,8 @@ KS_DEV u32 sk_place_window(const sk_args &A, u32 p, u64 h, sk_seq &q, const sk_b
         const u32 b = q.ls + __umulhi((u32)(h >> 32), q.mul);
         const u32 sh = (b & 1u) * 16u;
         const u32 o = (atomicAdd(&cnt[b >> 1], 1u << sh) >> sh) & 0xffffu; // two 16-bit counters per word
-        bo = (b << 16) | o; // b < 4096, o < 4096
+        const u32 srel = q.s - B.s_first;
+        bo = ((srel < 254u ? srel : 254u) << 24) | (b << 12) | o; // b, o < 4096
     }
     return bo;
 }
@@ -306,7 +318,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     // ---- phase 4: scatter kept hashes into bucket order
 #pragma unroll
     for (int i = 0; i < SK_E; i++)
-        if (bo[i] != 0xffffffffu) tmp[bstart(bo[i] >> 16) + (bo[i] & 0xffffu)] = h[i];
+        if (bo[i] != 0xffffffffu) tmp[bstart(SK_BO_B(bo[i])) + SK_BO_O(bo[i])] = h[i];
     __syncthreads();
 
     SK_STAMP_AT(4);
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
         pr[i] = 0xffffffffu;
         ab[i] = 0;
         if (bo[i] != 0xffffffffu) {
-            const u32 b = bo[i] >> 16, o = bo[i] & 0xffffu;
+            const u32 b = SK_BO_B(bo[i]), o = SK_BO_O(bo[i]);
             const u32 sb = bstart(b), c = bstart(b + 1) - sb;
             u32 p = sb, eq = 1, rep = 1;
             bool done = true;
@@ -512,6 +524,57 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
             A.out_abund[pos] = abund_s[d];
         }
     }
+    // ---- phase 9 (optional): the tile's postings, partitioned on one hash digit, into the regions of that digit.
+    // Everything LDS is free again: digit-sort the representatives through tmp so each digit leaves as one run.
+    if (A.part_keys) {
+        if (!B.in_lds) { // sequence ids do not fit the element code: let the host repartition this batch
+            if (tid == 0) atomicOr(&A.ticket[1], 2u);
+        } else {
+            u32 *bins = loff;               // [256] count per digit, then exclusive start inside the tile
+            __shared__ u32 gbase[256];
+            u16 *qrel = (u16 *)cnt;         // sequence (relative) of the element staged at tmp[pos]
+            __syncthreads();                // phase 8 finished reading tmp / abund_s
+            if (tid < 256) bins[tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SK_E; i++)
+                if (pr[i] != 0xffffffffu && (pr[i] & 1u))
+                    ab[i] = atomicAdd(&bins[(u32)(h[i] >> A.part_shift) & A.part_mask], 1u); // rank inside (tile, digit)
+            __syncthreads();
+            {
+                const u32 c = tid < 256 ? bins[tid] : 0;
+                u32 total;
+                const u32 ex = ks_block_excl_scan(c, scan_smem, &total);
+                if (tid < 256) {
+                    u32 off = 0;
+                    if (c) {
+                        off = atomicAdd(&A.part_cursor[tid], c);
+                        if ((u64)off + c > A.part_cap) atomicOr(&A.ticket[1], 2u); // region full: host falls back
+                    }
+                    gbase[tid] = off;
+                    bins[tid] = ex;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < SK_E; i++)
+                if (pr[i] != 0xffffffffu && (pr[i] & 1u)) {
+                    const u32 pos = bins[(u32)(h[i] >> A.part_shift) & A.part_mask] + ab[i];
+                    tmp[pos] = h[i];
+                    qrel[pos] = (u16)SK_BO_S(bo[i]);
+                }
+            __syncthreads();
+            for (u32 i = tid; i < n_distinct; i += SK_THREADS) {
+                const u64 hh = tmp[i];
+                const u32 dg = (u32)(hh >> A.part_shift) & A.part_mask;
+                const u64 slot = (u64)gbase[dg] + (i - bins[dg]);
+                if (slot < A.part_cap) {
+                    A.part_keys[(u64)dg * A.part_cap + slot] = hh;
+                    A.part_vals[(u64)dg * A.part_cap + slot] = s_first + qrel[i];
+                }
+            }
+        }
+    }
     SK_STAMP_AT(8);
 }
 
@@ -674,12 +737,25 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
 // before the tile kernel fixed their CSR positions); one workgroup per such sequence.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u64 *offs, const u64 *csr, const u64 *lg_hash,
-                                                    const u32 *lg_abund, u64 *hashes, u32 *abunds) {
+                                                    const u32 *lg_abund, u64 *hashes, u32 *abunds, u64 *part_keys,
+                                                    u32 *part_vals, u32 *part_cursor, u64 part_cap, u32 part_shift,
+                                                    u32 part_mask, u32 *status) {
     const u32 s = ids[blockIdx.x];
     const u64 dst = csr[s], n = csr[s + 1] - dst, src = offs[s];
     for (u64 i = threadIdx.x; i < n; i += 256) {
-        hashes[dst + i] = lg_hash[src + i];
+        const u64 h = lg_hash[src + i];
+        hashes[dst + i] = h;
         abunds[dst + i] = lg_abund[src + i];
+        if (part_keys) { // long sequences are rare: one device atomic per posting is fine here
+            const u32 dg = (u32)(h >> part_shift) & part_mask;
+            const u64 slot = atomicAdd(&part_cursor[dg], 1u);
+            if (slot < part_cap) {
+                part_keys[(u64)dg * part_cap + slot] = h;
+                part_vals[(u64)dg * part_cap + slot] = s;
+            } else {
+                atomicOr(&status[1], 2u);
+            }
+        }
     }
 }
 
@@ -709,7 +785,7 @@ __global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, 
 }
 
 int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, u32 max_seq_len,
-                          const ks_params *p, ks_sketches **out) {
+                          const ks_params *p, int part_pbits, ks_sketches **out) {
     KS_TRY(ks_check_params(ctx, p));
     if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
     if (((uintptr_t)d_res & 15) != 0) return ks_fail(ctx, KS_ERR_INVALID_ARG, "d_residues must be 16-byte aligned");
@@ -778,6 +854,26 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         }
         A.lut = ctx->d_lut + 256 * p->moltype;
         A.counts = counts;
+        SK_CHECK(ks_alloc(ctx, &ticket, 2));
+        SK_HIPCHECK(hipMemsetAsync(ticket, 0, 2 * sizeof(u32), ctx->stream));
+        A.ticket = ticket;
+        if (part_pbits > 0 && S->n_windows > 0 && S->n_windows < 0xffff0000ULL) {
+            // first partition digit: the low 8 bits of the join's hash prefix (the whole prefix if it is <= 8 bits)
+            const int dbits = part_pbits < 8 ? part_pbits : 8;
+            S->part_pbits = part_pbits;
+            S->part_shift = 64 - part_pbits;
+            S->part_regions = 1u << dbits;
+            const u64 per = S->n_windows / S->part_regions;
+            u64 cap = per + per / 4 + 8192;                 // uniform hashes fill regions evenly; skew -> fallback
+            cap = (cap + 8191) / 8192 * 8192;
+            S->part_cap = cap;
+            SK_CHECK(ks_alloc(ctx, &S->part_keys, (size_t)(cap * S->part_regions)));
+            SK_CHECK(ks_alloc(ctx, &S->part_vals, (size_t)(cap * S->part_regions)));
+            SK_CHECK(ks_alloc(ctx, &S->part_len, 256));
+            SK_HIPCHECK(hipMemsetAsync(S->part_len, 0, 256 * sizeof(u32), ctx->stream));
+            A.part_keys = S->part_keys; A.part_vals = S->part_vals; A.part_cursor = S->part_len; A.part_cap = cap;
+            A.part_shift = (u32)S->part_shift; A.part_mask = S->part_regions - 1;
+        }
 
         // ---- medium / long sequences first: their unique counts feed the tile kernel's CSR prefix
         if (n_med + n_long > 0) {
@@ -793,7 +889,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             SK_HIPCHECK(hipGetLastError());
         }
         if (n_med > 0) {
-            sk_args M = A;
+            sk_args M = A; // (keeps the posting arguments: a medium tile emits its own postings)
             M.out_hash = lg_hash; M.out_abund = lg_abund; M.len_cap = SK_MED_MAX; M.seq_list = med_ids;
             ks_timer_begin(ctx, "sketch_medium");
             hipLaunchKernelGGL(k_sketch_tiles<1>, dim3((u32)n_med), dim3(SK_THREADS), 0, ctx->stream, M);
@@ -827,15 +923,13 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         if (n_tiles > 0x7ffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "batch too large"); goto done; }
         SK_CHECK(ks_alloc(ctx, &tile_first, (size_t)n_tiles + 1));
         SK_CHECK(ks_alloc(ctx, &tile_status, (size_t)n_tiles));
-        SK_CHECK(ks_alloc(ctx, &ticket, 2));
         SK_HIPCHECK(hipMemsetAsync(tile_status, 0, (size_t)n_tiles * sizeof(unsigned long long), ctx->stream));
-        SK_HIPCHECK(hipMemsetAsync(ticket, 0, 2 * sizeof(u32), ctx->stream));
         ks_timer_begin(ctx, "tile_plan");
         hipLaunchKernelGGL(k_tile_plan, dim3((u32)((n_tiles + 256) / 256)), dim3(256), 0, ctx->stream, d_offs, n_seqs, (u32)n_tiles, tile_first);
         ks_timer_end(ctx);
         A.seq_list = tile_first; A.len_cap = SK_LS_MAX;
         A.out_hash = S->d_hashes; A.out_abund = S->d_abunds; A.csr = S->d_offsets;
-        A.tile_status = tile_status; A.ticket = ticket; A.n_tiles = (u32)n_tiles;
+        A.tile_status = tile_status; A.n_tiles = (u32)n_tiles;
         ks_timer_begin(ctx, "sketch_tiles");
         hipLaunchKernelGGL(k_sketch_tiles<0>, dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
         ks_timer_end(ctx);
@@ -844,14 +938,17 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         // ---- runs of medium / long sequences into their CSR slots
         if (n_med > 0) {
             ks_timer_begin(ctx, "place_long");
+            // medium runs: copy only (their tiles emitted their own postings)
             hipLaunchKernelGGL(k_place_long, dim3((u32)n_med), dim3(256), 0, ctx->stream, (const u32 *)med_ids, d_offs,
-                               (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds);
+                               (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds,
+                               (u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u64)0, 0u, 0u, ticket);
             ks_timer_end(ctx);
         }
         if (n_long > 0) {
             ks_timer_begin(ctx, "place_long");
             hipLaunchKernelGGL(k_place_long, dim3((u32)n_long), dim3(256), 0, ctx->stream, (const u32 *)long_ids, d_offs,
-                               (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds);
+                               (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds,
+                               A.part_keys, A.part_vals, A.part_cursor, A.part_cap, A.part_shift, A.part_mask, ticket);
             ks_timer_end(ctx);
         }
         SK_HIPCHECK(hipGetLastError());
@@ -860,7 +957,15 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin + 1, ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
         SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
         S->n_hashes = ctx->h_pin[0];
-        if (((u32 *)(ctx->h_pin + 1))[1] != 0) { st = ks_fail(ctx, KS_ERR_HIP, "sketch: tile look-back timed out"); goto done; }
+        {
+            const u32 status = ((u32 *)(ctx->h_pin + 1))[1];
+            if (status & 1u) { st = ks_fail(ctx, KS_ERR_HIP, "sketch: tile look-back timed out"); goto done; }
+            if (status & 2u) { // a region overflowed (skewed hashes) or a tile could not code its sequences: no postings,
+                               // ks_search repartitions from the CSR instead
+                ks_pool_free(ctx, S->part_keys); ks_pool_free(ctx, S->part_vals); ks_pool_free(ctx, S->part_len);
+                S->part_keys = nullptr; S->part_vals = nullptr; S->part_len = nullptr; S->part_pbits = 0;
+            }
+        }
     }
 
 done:

@@ -119,6 +119,15 @@ class Context:
     def synchronize(self):
         self._check(self._L.ks_ctx_synchronize(self._h))
 
+    def to_device(self, a: np.ndarray) -> "DeviceBuffer":
+        """Copy a host array into a plain device buffer (for the *_device entry points without torch)."""
+        a = np.ascontiguousarray(a)
+        p = C.c_void_p()
+        self._check(self._L.ks_dev_malloc(self._h, a.nbytes, C.byref(p)))
+        buf = DeviceBuffer(self, p, a.nbytes)
+        self._check(self._L.ks_dev_upload(self._h, p, _ptr(a), a.nbytes))
+        return buf
+
     def pool_stats(self) -> Dict[str, int]:
         v = [C.c_uint64(0) for _ in range(4)]
         self._check(self._L.ks_ctx_pool_stats(self._h, *[C.byref(x) for x in v]))
@@ -141,6 +150,14 @@ class Context:
         out = C.c_void_p()
         self._check(self._L.ks_sketch_batch_device(self._h, C.c_void_p(d_residues), C.c_void_p(d_offsets), n_seqs,
                                                    n_residues, max_seq_len, C.byref(p), C.byref(out)))
+        return Sketches(self, out)
+
+    def sketch_queries_device(self, index: "Index", d_residues: int, d_offsets: int, n_seqs: int, n_residues: int,
+                              max_seq_len: int = 0) -> "Sketches":
+        """Sketch a query batch for an immediate search against `index` (also emits pre-partitioned postings)."""
+        out = C.c_void_p()
+        self._check(self._L.ks_sketch_queries_device(self._h, index._h, C.c_void_p(d_residues), C.c_void_p(d_offsets),
+                                                     n_seqs, n_residues, max_seq_len, C.byref(out)))
         return Sketches(self, out)
 
     def sketches_from_host(self, offsets: np.ndarray, hashes: np.ndarray, abunds: np.ndarray, ksize: int,
@@ -198,6 +215,26 @@ class Context:
         return {rows[i].name.decode(): (int(rows[i].launches), float(rows[i].total_ms)) for i in range(min(n.value, 64))}
 
 
+class DeviceBuffer:
+    def __init__(self, ctx: Context, ptr, nbytes: int):
+        self._ctx, self._p, self.nbytes = ctx, ptr, nbytes
+
+    @property
+    def ptr(self) -> int:
+        return int(self._p.value or 0)
+
+    def free(self):
+        if self._p is not None and self._ctx._h:
+            self._ctx._L.ks_dev_free(self._ctx._h, self._p)
+        self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class _Owned:
     _free = None
 
@@ -231,6 +268,10 @@ class Sketches(_Owned):
     @property
     def n_windows(self) -> int:
         return int(self._ctx._L.ks_sketches_n_windows(self._h))
+
+    @property
+    def has_postings(self) -> bool:
+        return bool(self._ctx._L.ks_sketches_has_postings(self._h))
 
     def union(self) -> "Sketches":
         """Combined sketch: sorted unique hashes of all sequences with summed abundances (one sequence)."""

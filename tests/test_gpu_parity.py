@@ -256,3 +256,64 @@ def test_full_size_properties(ctx):
     # oracle spot check on a slice
     w = oracle.sketch_batch(sub_res[:int(sub_offs[2000])], sub_offs[:2001], k, scaled, mol, n_threads=8)
     assert np.array_equal(h3[:len(w[1])], w[1])
+
+
+@pytest.mark.parametrize("k,scaled,mol,nt,nq", [
+    (10, 1, "protein", 300, 2000),      # tiny index: pbits <= 8, the sketch kernel's regions are the join buckets
+    (10, 1, "protein", 6000, 5000),     # 8 < pbits <= 16: one segmented pass finishes the partition
+    (16, 5, "dayhoff", 20000, 20000),
+    (24, 5, "hp", 8000, 8000),
+    (5, 1, "hp", 150, 120),             # saturated alphabet, tiny index (pbits = 1)
+])
+def test_presorted_query_postings_equal_plain_search(ctx, k, scaled, mol, nt, nq):
+    """ks_sketch_queries_device (postings partitioned inside the sketch kernel) gives the same sketches and the same
+    hits as sketch + search without them, including when it has to fall back."""
+    t_res, t_off = synth.proteome(nt, stream=90 + k)
+    q_res, q_off = synth.queries(nq, t_res, t_off, stream=91 + k)
+    if k == 10 and nt == 6000:  # medium / long query sequences exercise their own emission paths
+        rng = np.random.default_rng(3)
+        extra = [bytes(rng.choice(list(b"ACDEFGHIKLMNPQRSTVWY"), size=n).tolist()) for n in (1600, 4000, 4090, 9000)]
+        seqs = [bytes(q_res[int(q_off[i]):int(q_off[i + 1])]) for i in range(nq)]
+        seqs = seqs[:100] + extra[:2] + seqs[100:] + extra[2:]
+        q_res, q_off = ks.pack(seqs)
+    T = ctx.sketch_batch(t_res, t_off, k, scaled, mol)
+    ix = ctx.index_build(T)
+    plain_Q = ctx.sketch_batch(q_res, q_off, k, scaled, mol)
+    want = ctx.search(ix, plain_Q).to_host()
+    d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
+    Q = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
+    assert Q.has_postings
+    for g, w in zip(Q.to_host(), plain_Q.to_host()):
+        assert np.array_equal(g, w)
+    got = ctx.search(ix, Q).to_host()
+    assert len(want[0]) > 0
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    # and against the oracle for the small cases
+    if nt <= 6000:
+        wq = oracle.sketch_batch(q_res, q_off, k, scaled, mol, n_threads=8)
+        wt = oracle.sketch_batch(t_res, t_off, k, scaled, mol, n_threads=8)
+        ow = oracle.manysearch(wq[0], wq[1], wt[0], wt[1], wt[2], n_threads=8)
+        for g, w in zip(got, ow):
+            assert np.array_equal(g, w)
+
+
+def test_presorted_postings_fall_back_on_skewed_hashes(ctx):
+    """20000 copies of one protein: ~290 distinct hashes land in a few of the 256 fixed-size regions and overflow them.
+    The postings are dropped, the sketches are still exactly right, and ks_search partitions from the CSR instead."""
+    t_res, t_off = synth.proteome(30000, stream=95)
+    one = bytes(t_res[int(t_off[7]):int(t_off[8])])
+    q_res, q_off = ks.pack([one] * 20000)
+    T = ctx.sketch_batch(t_res, t_off, 10, 1, "protein")
+    ix = ctx.index_build(T)
+    d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
+    Q = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
+    assert not Q.has_postings
+    o, m, a = Q.to_host()
+    w1 = oracle.sketch_protein(one, 10, 1, "protein")
+    n1 = len(w1[0])
+    assert np.array_equal(o, np.arange(20001, dtype=np.uint64) * np.uint64(n1))
+    assert np.array_equal(m.reshape(20000, n1), np.tile(w1[0], (20000, 1)))
+    qid, tid, isect, nw = ctx.search(ix, Q).to_host()
+    self_hits = tid == 7
+    assert self_hits.sum() == 20000 and np.all(isect[self_hits] == n1)

@@ -31,7 +31,10 @@ def child(args):
     ix = ctx.index_build(T)
 
     def step():
-        Q = ctx.sketch_batch_device(dq_res.data_ptr(), dq_off.data_ptr(), len(q_off) - 1, len(q_res), k, sc, mol)
+        if args.plain:
+            Q = ctx.sketch_batch_device(dq_res.data_ptr(), dq_off.data_ptr(), len(q_off) - 1, len(q_res), k, sc, mol)
+        else:
+            Q = ctx.sketch_queries_device(ix, dq_res.data_ptr(), dq_off.data_ptr(), len(q_off) - 1, len(q_res))
         H = ctx.search(ix, Q)
         r = (Q.n_hashes, H.count, H.n_pair_instances)
         H.free(); Q.free()
@@ -72,6 +75,7 @@ def main():
     ap.add_argument("--cache", default="/tmp/ks_mb")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("--no-events", action="store_true")
+    ap.add_argument("--plain", action="store_true", help="sketch without pre-partitioned postings")
     ap.add_argument("--variant", default="base")
     args = ap.parse_args()
     if args.child:
@@ -95,7 +99,7 @@ def main():
         env = dict(os.environ, KMERSEEK_AMD_LIB=so)
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--variant", v, "--cache", cache,
                "--ksize", str(args.ksize), "--scaled", str(args.scaled), "--moltype", args.moltype,
-               "--steps", str(args.steps)] + (["--no-events"] if args.no_events else [])
+               "--steps", str(args.steps)] + (["--no-events"] if args.no_events else []) + (["--plain"] if args.plain else [])
         subprocess.call(cmd, env=env, timeout=300)
         sys.stdout.flush()
 
