@@ -110,6 +110,12 @@ done:
 #endif
 //                          index keys staged per chunk: 48 KiB of LDS -> 3 workgroups (24 waves) per CU
 
+static int bits_for(u32 n) { // bits needed to represent ids 0..n-1
+    int b = 0;
+    while (b < 32 && (n > (1u << b))) b++;
+    return b < 1 ? 1 : b;
+}
+
 int ks_join_pbits(u64 n_postings) { // buckets of ~3k index postings; the query side is partitioned on the same bits
     int pbits = 0;
     while (pbits < 16 && (n_postings >> pbits) > 3072) pbits++;
@@ -160,7 +166,8 @@ KS_DEV u32 jn_lower_bound_lds(const u64 *lk, u32 n, u64 h) {
 __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, const u32 *qids, const u64 *ikeys,
                                                              const u32 *itids, const u32 *iabunds, const u64 *q_lo,
                                                              const u64 *q_hi, const u64 *dir_t, u64 *pair_keys,
-                                                             u32 *pair_vals, u64 cap, unsigned long long *cursor) {
+                                                             u32 *pair_vals, u64 cap, unsigned long long *cursor,
+                                                             int tbits) {
     __shared__ u64 lk[JN_CAP];
     __shared__ u32 scan_smem[JN_THREADS / 64 + 1];
     __shared__ unsigned long long base_s;
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
                         const u64 j0 = c0 + (info[e] & 0xffffu);
                         for (u32 j = 0; j < c; j++, slot++) {
                             if (slot < cap) {
-                                pair_keys[slot] = ((u64)q << 32) | itids[j0 + j];
+                                pair_keys[slot] = ((u64)q << tbits) | itids[j0 + j]; // ids packed tight: fewer sort passes
                                 pair_vals[slot] = iabunds[j0 + j];
                             }
                         }
@@ -239,23 +246,17 @@ __global__ __launch_bounds__(256) void k_pair_rows(const u64 *keys, const u32 *v
 }
 
 __global__ __launch_bounds__(256) void k_pair_emit(const u64 *keys, const u32 *vals, const u64 *row_start, u32 n_rows,
-                                                   u32 *qid, u32 *tid, u32 *isect, u64 *nw) {
+                                                   u32 *qid, u32 *tid, u32 *isect, u64 *nw, int tbits) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     u64 b = row_start[r], e = row_start[r + 1];
     u64 k = keys[b];
     u64 w = 0;
     for (u64 j = b; j < e; j++) w += vals[j];
-    qid[r] = (u32)(k >> 32);
-    tid[r] = (u32)k;
+    qid[r] = (u32)(k >> tbits);
+    tid[r] = (u32)(k & ((1ULL << tbits) - 1ULL));
     isect[r] = (u32)(e - b);
     nw[r] = w;
-}
-
-static int bits_for(u32 n) { // bits needed to represent ids 0..n-1
-    int b = 0;
-    while (b < 32 && (n > (1u << b))) b++;
-    return b < 1 ? 1 : b;
 }
 
 int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out) {
@@ -284,6 +285,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         // ---- query postings grouped on the top pbits hash bits (the join needs locality, not order)
         const int pbits = ks_join_pbits(n_t);
         const u32 n_buckets = 1u << pbits;
+        const int tbits = bits_for(ix->n_targets); // pair key = qid << tbits | tid
         u64 *qk = nullptr;
         u32 *qv = nullptr;
         const u64 *q_lo = nullptr, *q_hi = nullptr;
@@ -338,7 +340,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
             ks_timer_begin(ctx, "join_buckets");
             hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
                                (const u32 *)qv, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds,
-                               q_lo, q_hi, (const u64 *)dir_t, pk0, pv0, cap, cursor);
+                               q_lo, q_hi, (const u64 *)dir_t, pk0, pv0, cap, cursor, tbits);
             ks_timer_end(ctx);
             SE_HIP(hipGetLastError());
             SE_HIP(hipMemcpyAsync(ctx->h_pin, cursor, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
@@ -366,10 +368,8 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         u64 *pk = nullptr;
         u32 *pv = nullptr;
         {
-            const int tb = (bits_for(ix->n_targets) + 7) / 8 * 8, qb = (bits_for(q->n_seqs) + 7) / 8 * 8;
             int shifts[8], ns = 0;
-            for (int sh = 0; sh < tb; sh += 8) shifts[ns++] = sh;
-            for (int sh = 32; sh < 32 + qb; sh += 8) shifts[ns++] = sh;
+            for (int sh = 0; sh < tbits + bits_for(q->n_seqs); sh += 8) shifts[ns++] = sh;
             // the match list (pk0, pv0) is scratch from here on: ping-pong with (pk1, pv1)
             SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_PAIRS, pk0, pv0, pk0, pv0, pk1, pv1, n_pairs, shifts, ns, &pk, &pv));
         }
@@ -394,7 +394,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         ks_timer_end(ctx);
         ks_timer_begin(ctx, "pair_emit");
         hipLaunchKernelGGL(k_pair_emit, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv,
-                           (const u64 *)row_start, n_rows, H->d_qid, H->d_tid, H->d_isect, H->d_nw);
+                           (const u64 *)row_start, n_rows, H->d_qid, H->d_tid, H->d_isect, H->d_nw, tbits);
         ks_timer_end(ctx);
         SE_HIP(hipGetLastError());
         SE_HIP(hipStreamSynchronize(ctx->stream));
