@@ -199,6 +199,10 @@ void ks_index_free(ks_index *ix);
 int ks_search(ks_ctx *ctx, const ks_index *index, const ks_sketches *queries, ks_hits **out);
 uint64_t ks_hits_count(const ks_hits *h);
 uint64_t ks_hits_n_pair_instances(const ks_hits *h); /* Σ_h q(h)·t(h): matched (posting, posting) pairs */
+/* how the query postings were grouped for the join (results are identical on every path):
+ * 0 the sketch kernel's regions were the buckets; 1 regions + one histogram-free bucket scatter;
+ * 2 regions + one dense radix pass (a bucket overflowed); 3 dense radix partition from the CSR (no postings attached) */
+int ks_hits_partition_path(const ks_hits *h);
 int ks_hits_copy_to_host(ks_ctx *ctx, const ks_hits *h, uint32_t *qid, uint32_t *tid,
                          uint32_t *intersect, uint64_t *n_weighted);
 void ks_hits_free(ks_hits *h);

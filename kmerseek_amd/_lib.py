@@ -91,6 +91,7 @@ SIGNATURES = {
     "ks_search": (C.c_int, [_vp, _vp, _vp, _pp]),
     "ks_hits_count": (C.c_uint64, [_vp]),
     "ks_hits_n_pair_instances": (C.c_uint64, [_vp]),
+    "ks_hits_partition_path": (C.c_int, [_vp]),
     "ks_hits_copy_to_host": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ks_hits_free": (None, [_vp]),
     "ks_timing_enable": (C.c_int, [_vp, C.c_int]),

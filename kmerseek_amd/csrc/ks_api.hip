@@ -298,6 +298,7 @@ extern "C" int ks_search(ks_ctx *ctx, const ks_index *index, const ks_sketches *
 }
 extern "C" uint64_t ks_hits_count(const ks_hits *h) { return h ? h->n_hits : 0; }
 extern "C" uint64_t ks_hits_n_pair_instances(const ks_hits *h) { return h ? h->n_pair_instances : 0; }
+extern "C" int ks_hits_partition_path(const ks_hits *h) { return h ? h->partition_path : -1; }
 extern "C" int ks_hits_copy_to_host(ks_ctx *ctx, const ks_hits *h, uint32_t *qid, uint32_t *tid, uint32_t *intersect,
                                     uint64_t *n_weighted) {
     if (!ctx || !h) return KS_ERR_INVALID_ARG;

@@ -107,14 +107,15 @@ struct ks_sketches {
     u64 *d_hashes;  // n_hashes
     u32 *d_abunds;  // n_hashes
     // optional, made by ks_sketch_queries_device: postings (hash, seq) already partitioned on hash bits
-    // [part_shift, part_shift + 8) into part_regions fixed-capacity regions (region r holds part_len[r] records
+    // low 8 bits of the join prefix (ks_join_prefix) into part_regions fixed-capacity regions (region r holds part_len[r] records
     // starting at r * part_cap) — the first partition pass of a search against an index that joins on part_pbits bits
     u64 *part_keys;
     u32 *part_vals;
     u32 *part_len;  // device, [part_regions]
     u64 part_cap;
     u32 part_regions;
-    int part_pbits, part_shift;
+    int part_pbits;
+    u32 part_K;     // ks_join_prefix multiplier the regions were cut with
 };
 
 struct ks_index {
@@ -131,6 +132,7 @@ struct ks_hits {
     ks_ctx *ctx;
     u64 n_hits;
     u64 n_pair_instances;
+    int partition_path; // how the query postings reached their join buckets (see ks_hits_partition_path)
     u32 *d_qid, *d_tid, *d_isect;
     u64 *d_nw;
 };
@@ -161,7 +163,11 @@ struct ks_rs_segments {
 };
 int ks_radix_sort_u32(ks_ctx *ctx, int tag, const u64 *keys_in, const u32 *vals_in, u64 *ka, u32 *va, u64 *kb, u32 *vb,
                       u64 n, const int *shifts, int n_shifts, u64 **keys_out, u32 **vals_out,
-                      const ks_rs_segments *seg = nullptr);
+                      const ks_rs_segments *seg = nullptr, u32 pfxK = 0);
+// last partition pass of a search without a histogram: segmented input -> 2^pbits buckets of capacity bcap;
+// bcur[bucket] ends as the bucket's record count, status[1] != 0 if some bucket overflowed
+int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, const ks_rs_segments *seg, int shift,
+                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status);
 int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_in, u64 *ka, u64 *va, u64 *kb, u64 *vb,
                       u64 n, const int *shifts, int n_shifts, u64 **keys_out, u64 **vals_out);
 
@@ -171,6 +177,8 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                           u32 max_seq_len, const ks_params *p, int part_pbits, ks_sketches **out);
 // bits of hash prefix the join against an index of n_postings uses (buckets of ~3k index postings, <= 16)
 int ks_join_pbits(u64 n_postings);
+// multiplier of ks_join_prefix (ks_device.h) for a join on pbits prefix bits of hashes kept below max_hash
+u32 ks_join_prefix_mul(int pbits, u64 max_hash);
 int ks_kmerpos_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,
                            const ks_params *p, ks_kmerpos **out);
 int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out);

@@ -94,3 +94,12 @@ KS_DEV u32 ks_lane_lt_count(u64 mask) {
     // number of set bits of mask in lanes below this one
     return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0));
 }
+
+// Join prefix of a kept hash: floor(h * 2^pbits / (max_hash + 1)) computed on the top 32 bits — uniform over
+// [0, 2^pbits) for every `scaled` (kept hashes only span [0, max_hash], so plain top bits are NOT uniform for scaled > 1).
+// K = floor(2^(pbits+32) / ((max_hash >> 32) + 1)); for scaled = 1 this is exactly h >> (64 - pbits).  Monotone in h.
+KS_DEV u32 ks_join_prefix(u64 h, u32 K) { return __umulhi((u32)(h >> 32), K); }
+// digit of a radix pass: plain key bits (K == 0) or bits [shift, shift + 8) of the join prefix
+KS_DEV u32 ks_rs_digit(u64 key, int shift, u32 K) {
+    return K ? ((ks_join_prefix(key, K) >> shift) & 255u) : ((u32)(key >> shift) & 255u);
+}

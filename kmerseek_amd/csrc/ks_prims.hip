@@ -180,7 +180,7 @@ KS_DEV void rs_tile_geom(u64 n, const u32 *seg_len, u64 seg_cap, u32 tiles_per_s
 // hist[d * nblocks + block] = number of keys of this block's tile with digit d
 template <int TAG>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 *hist, u64 n, int shift, u32 nblocks,
-                                                           const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg) {
+                                                           const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg, u32 pfxK) {
     __shared__ u32 bins[256];
     if (threadIdx.x < 256) bins[threadIdx.x] = 0;
     __syncthreads();
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 
 #pragma unroll
     for (int i = 0; i < RS_IPT; i++) {
         const u32 li = (u32)i * RS_THREADS + threadIdx.x;
-        if (li < nvalid) atomicAdd(&bins[(u32)(keys[base + li] >> shift) & 255u], 1u);
+        if (li < nvalid) atomicAdd(&bins[ks_rs_digit(keys[base + li], shift, pfxK)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 256) hist[(u64)threadIdx.x * nblocks + blockIdx.x] = bins[threadIdx.x];
@@ -200,10 +200,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 
 // ranks computed per wave with ballot-matching + per-wave digit counters preserve input order.
 // Records are staged through ONE LDS buffer in local digit order (keys first, then values), so each
 // digit leaves the tile as a contiguous run of full cache lines.
-template <typename V, int TAG>
+// BUCKETS = true: the last partition pass of a search.  The input is segmented by the LOW digit (region r), this pass
+// splits on the HIGH digit d, and the output is not a dense sorted array but 2^pbits fixed-capacity buckets
+// (bucket (d << 8 | r) at bucket * bcap): each tile reserves its slice of a bucket with one atomic per digit, so
+// there is no histogram pass and no scan (order inside a bucket is irrelevant to the join).  A bucket that would
+// overflow raises status[1] and the host redoes the pass the dense way.
+template <typename V, int TAG, bool BUCKETS>
 __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64 *kin, const V *vin, u64 *kout, V *vout,
                                                               const u32 *goffs, u64 n, int shift, u32 nblocks,
-                                                              const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg) {
+                                                              const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg,
+                                                              u32 *bcur, u32 bcap, unsigned long long *status, u32 pfxK) {
     __shared__ u32 wcnt[RS_WAVES][256];
     __shared__ u32 dstart[256];
     __shared__ u32 gbase[256];
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 256) {
         for (int w = 0; w < RS_WAVES; w++) wcnt[w][tid] = 0;
-        gbase[tid] = goffs[(u64)tid * nblocks + blockIdx.x];
+        if (!BUCKETS) gbase[tid] = goffs[(u64)tid * nblocks + blockIdx.x];
     }
     __syncthreads();
 
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
 #pragma unroll
     for (int r = 0; r < RS_IPT; r++) {
         const u32 li = wloc + (u32)r * 64 + lane;
-        u32 d = li < nvalid ? ((u32)(key[r] >> shift) & 255u) : 255u;
+        u32 d = li < nvalid ? ks_rs_digit(key[r], shift, pfxK) : 255u;
         // lanes holding the same digit
         u64 peers = ~0ULL;
 #pragma unroll
@@ -263,6 +269,17 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
         u32 ds = ks_block_excl_scan(tot, scan_smem, &total);
         if (tid < 256) {
             dstart[tid] = ds;
+            if (BUCKETS) { // reserve [base, base + tot) of bucket (digit << 8 | region); invalid tail records sit in digit 255
+                u32 mine = tot;
+                if (tid == 255) mine -= RS_TILE - nvalid;
+                u32 base = 0;
+                if (mine) {
+                    const u32 bucket = (tid << 8) | (blockIdx.x / tiles_per_seg);
+                    base = atomicAdd(&bcur[bucket], mine);
+                    if (base + mine > bcap) atomicOr(&status[1], 1ULL);
+                }
+                gbase[tid] = base;
+            }
 #pragma unroll
             for (int w = 0; w < RS_WAVES; w++) { wcnt[w][tid] = ds; ds += c[w]; }
         }
@@ -275,16 +292,21 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
         stage[pos[r]] = key[r];
     }
     __syncthreads();
-    u32 gdst[RS_IPT]; // global destination of local slot i*RS_THREADS + tid
+    u64 gdst[RS_IPT]; // global destination of local slot i*RS_THREADS + tid
 #pragma unroll
     for (int i = 0; i < RS_IPT; i++) {
         u32 p = (u32)i * RS_THREADS + tid;
-        gdst[i] = 0xffffffffu;
+        gdst[i] = ~0ULL;
         if (p < nvalid) {
             u64 k = stage[p];
-            u32 d = (u32)(k >> shift) & 255u;
-            gdst[i] = gbase[d] + (p - dstart[d]);
-            kout[gdst[i]] = k;
+            u32 d = ks_rs_digit(k, shift, pfxK);
+            if (BUCKETS) {
+                const u32 slot = gbase[d] + (p - dstart[d]);
+                if (slot < bcap) gdst[i] = (u64)((d << 8) | (blockIdx.x / tiles_per_seg)) * bcap + slot;
+            } else {
+                gdst[i] = (u64)gbase[d] + (p - dstart[d]);
+            }
+            if (gdst[i] != ~0ULL) kout[gdst[i]] = k;
         }
     }
     __syncthreads();
@@ -295,7 +317,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
 #pragma unroll
     for (int i = 0; i < RS_IPT; i++) {
         u32 p = (u32)i * RS_THREADS + tid;
-        if (gdst[i] != 0xffffffffu) vout[gdst[i]] = vstage[p];
+        if (gdst[i] != ~0ULL) vout[gdst[i]] = vstage[p];
     }
 }
 
@@ -303,7 +325,8 @@ static const char *const rs_tag_names[3] = {"index", "qpart", "pairs"};
 
 template <typename V, int TAG>
 static int radix_sort_tagged(ks_ctx *ctx, const u64 *keys_in, const V *vals_in, u64 *ka, V *va, u64 *kb, V *vb, u64 n,
-                             const int *shifts, int n_shifts, u64 **keys_out, V **vals_out, const ks_rs_segments *seg) {
+                             const int *shifts, int n_shifts, u64 **keys_out, V **vals_out, const ks_rs_segments *seg,
+                             u32 pfxK) {
     *keys_out = (u64 *)keys_in;
     *vals_out = (V *)vals_in;
     if (n <= 1 || n_shifts <= 0) return KS_OK;
@@ -329,13 +352,14 @@ static int radix_sort_tagged(ks_ctx *ctx, const u64 *keys_in, const V *vals_in, 
         const u64 s_cap = segmented ? seg->cap : 0;
         ks_timer_begin(ctx, nm_hist.c_str());
         hipLaunchKernelGGL((k_radix_hist<TAG>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, kin, hist, n, shifts[i], nblocks,
-                           s_len, s_cap, tiles_per_seg);
+                           s_len, s_cap, tiles_per_seg, pfxK);
         ks_timer_end(ctx);
         st = ks_scan_u32_inplace(ctx, hist, (u64)256 * nblocks, nullptr);
         if (st != KS_OK) break;
         ks_timer_begin(ctx, nm_scat.c_str());
-        hipLaunchKernelGGL((k_radix_scatter<V, TAG>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, kin, vin, kout, vout,
-                           (const u32 *)hist, n, shifts[i], nblocks, s_len, s_cap, tiles_per_seg);
+        hipLaunchKernelGGL((k_radix_scatter<V, TAG, false>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, kin, vin, kout, vout,
+                           (const u32 *)hist, n, shifts[i], nblocks, s_len, s_cap, tiles_per_seg, (u32 *)nullptr, 0u,
+                           (unsigned long long *)nullptr, pfxK);
         ks_timer_end(ctx);
         if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "radix sort launch failed");
         kin = kout;
@@ -349,13 +373,27 @@ static int radix_sort_tagged(ks_ctx *ctx, const u64 *keys_in, const V *vals_in, 
 }
 
 int ks_radix_sort_u32(ks_ctx *ctx, int tag, const u64 *keys_in, const u32 *vals_in, u64 *ka, u32 *va, u64 *kb, u32 *vb, u64 n,
-                      const int *shifts, int n_shifts, u64 **keys_out, u32 **vals_out, const ks_rs_segments *seg) {
+                      const int *shifts, int n_shifts, u64 **keys_out, u32 **vals_out, const ks_rs_segments *seg, u32 pfxK) {
     if (tag == KS_SORT_QPART)
-        return radix_sort_tagged<u32, KS_SORT_QPART>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out, seg);
-    return radix_sort_tagged<u32, KS_SORT_PAIRS>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out, seg);
+        return radix_sort_tagged<u32, KS_SORT_QPART>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out, seg, pfxK);
+    return radix_sort_tagged<u32, KS_SORT_PAIRS>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out, seg, pfxK);
 }
 int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_in, u64 *ka, u64 *va, u64 *kb, u64 *vb, u64 n,
                       const int *shifts, int n_shifts, u64 **keys_out, u64 **vals_out) {
     (void)tag;
-    return radix_sort_tagged<u64, KS_SORT_INDEX>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out, nullptr);
+    return radix_sort_tagged<u64, KS_SORT_INDEX>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out, nullptr, 0u);
+}
+
+// One pass, no histogram: segmented postings (regions by the low digit) -> 2^pbits fixed-capacity buckets.
+int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, const ks_rs_segments *seg, int shift,
+                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status) {
+    const u32 tiles_per_seg = (u32)((seg->cap + RS_TILE - 1) / RS_TILE);
+    const u32 nblocks = seg->regions * tiles_per_seg;
+    ks_timer_begin(ctx, "radix_scatter.qpart");
+    hipLaunchKernelGGL((k_radix_scatter<u32, KS_SORT_QPART, true>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in,
+                       bkeys, bvals, (const u32 *)nullptr, (u64)0, shift, nblocks, seg->len, seg->cap, tiles_per_seg, bcur, bcap,
+                       status, pfxK);
+    ks_timer_end(ctx);
+    KS_HIP(ctx, hipGetLastError());
+    return KS_OK;
 }

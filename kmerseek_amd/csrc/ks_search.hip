@@ -122,6 +122,12 @@ int ks_join_pbits(u64 n_postings) { // buckets of ~3k index postings; the query 
     return pbits;
 }
 
+u32 ks_join_prefix_mul(int pbits, u64 max_hash) {
+    const u64 den = (max_hash >> 32) + 1ULL;
+    const u64 K = pbits >= 32 ? 0xffffffffULL : ((1ULL << (pbits + 32)) / den);
+    return K > 0xffffffffULL ? 0xffffffffu : (u32)K; // smaller only coarsens (still < 2^pbits, still monotone)
+}
+
 // query-side bucket bounds when the sketch kernel's regions ARE the buckets (pbits <= 8): no partition pass at all
 __global__ __launch_bounds__(256) void k_region_dir(const u32 *len, u64 cap, u32 n_regions, u64 *lo, u64 *hi) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -130,17 +136,16 @@ __global__ __launch_bounds__(256) void k_region_dir(const u32 *len, u64 cap, u32
     hi[b] = (u64)b * cap + len[b];
 }
 
-// dir[b] = first posting whose top `pbits` bits are >= b, for b in [0, 2^pbits]; keys are ordered on those bits
-__global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int pbits, u64 *dir) {
+// dir[b] = first posting whose join prefix is >= b, for b in [0, 2^pbits]; keys are ordered on the prefix
+__global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int pbits, u32 pfxK, u64 *dir) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 nb = 1u << pbits;
     if (b > nb) return;
     if (b == nb) { dir[b] = n; return; }
-    const int sh = 64 - pbits;
     u64 lo = 0, hi = n;
     while (lo < hi) {
         u64 mid = lo + ((hi - lo) >> 1);
-        u64 pre = pbits ? (keys[mid] >> sh) : 0;
+        u32 pre = pbits ? ks_join_prefix(keys[mid], pfxK) : 0;
         if (pre < b) lo = mid + 1; else hi = mid;
     }
     dir[b] = lo;
@@ -270,7 +275,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
     H->ctx = ctx;
     const u64 n_q = q->n_hashes, n_t = ix->n_postings;
     u64 *qk0 = nullptr, *qk1 = nullptr, *pk0 = nullptr, *pk1 = nullptr, *row_start = nullptr, *dir_q = nullptr, *dir_t = nullptr;
-    u32 *qv0 = nullptr, *qv1 = nullptr, *pv0 = nullptr, *pv1 = nullptr, *heads = nullptr, *d_nrows = nullptr;
+    u32 *qv0 = nullptr, *qv1 = nullptr, *pv0 = nullptr, *pv1 = nullptr, *heads = nullptr, *d_nrows = nullptr, *bcur = nullptr;
     unsigned long long *cursor = nullptr;
     int st = KS_OK;
 #define SE_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
@@ -286,77 +291,107 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         const int pbits = ks_join_pbits(n_t);
         const u32 n_buckets = 1u << pbits;
         const int tbits = bits_for(ix->n_targets); // pair key = qid << tbits | tid
-        u64 *qk = nullptr;
-        u32 *qv = nullptr;
-        const u64 *q_lo = nullptr, *q_hi = nullptr;
+        const u32 pfxK = ks_join_prefix_mul(pbits, ks_max_hash(ix->params.scaled));
         SE_CHECK(ks_alloc(ctx, &dir_q, (size_t)2 * n_buckets + 2));
         SE_CHECK(ks_alloc(ctx, &dir_t, (size_t)n_buckets + 1));
-        const bool pre = q->part_keys && q->part_pbits == pbits && pbits > 0;
-        if (pre && pbits <= 8) {
-            // the sketch kernel already wrote one region per bucket
-            qk = q->part_keys; qv = q->part_vals;
-            ks_timer_begin(ctx, "bucket_dir");
-            hipLaunchKernelGGL(k_region_dir, dim3((n_buckets + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)q->part_len,
-                               q->part_cap, n_buckets, dir_q, dir_q + n_buckets);
-            ks_timer_end(ctx);
-            q_lo = dir_q; q_hi = dir_q + n_buckets;
-        } else {
-            SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qk1, (size_t)n_q));
-            SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qv1, (size_t)n_q));
-            if (pre) {
-                // the sketch kernel did the low digit; one segmented pass on the remaining high bits finishes the job
-                const int shifts[1] = {64 - pbits + 8};
-                ks_rs_segments seg{q->part_len, q->part_cap, q->part_regions};
-                SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_QPART, q->part_keys, q->part_vals, qk1, qv1, qk0, qv0, n_q, shifts, 1,
-                                           &qk, &qv, &seg));
-            } else {
-                ks_timer_begin(ctx, "fill_query_vals");
-                hipLaunchKernelGGL(k_fill_query_vals, dim3((q->n_seqs + 3) / 4), dim3(256), 0, ctx->stream, (const u64 *)q->d_offsets, q->n_seqs, qv0);
-                ks_timer_end(ctx);
-                SE_HIP(hipGetLastError());
-                // hashes are read straight from the query sketches on the first pass (no staging copy);
-                // qv0 holds the input qids, so the first pass lands in (qk1, qv1)
-                int shifts[2], ns = 0;
-                for (int sh = 64 - pbits; sh < 64; sh += 8) shifts[ns++] = sh;
-                SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_QPART, q->d_hashes, qv0, qk1, qv1, qk0, qv0, n_q, shifts, ns, &qk, &qv));
-            }
-            ks_timer_begin(ctx, "bucket_dir");
-            hipLaunchKernelGGL(k_bucket_dir, dim3((n_buckets + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)qk, n_q, pbits, dir_q);
-            ks_timer_end(ctx);
-            q_lo = dir_q; q_hi = dir_q + 1;
-        }
+        SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, 2)); // [0] matches appended, [1] a query bucket overflowed
         ks_timer_begin(ctx, "bucket_dir");
-        hipLaunchKernelGGL(k_bucket_dir, dim3((n_buckets + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys, n_t, pbits, dir_t);
+        hipLaunchKernelGGL(k_bucket_dir, dim3((n_buckets + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys, n_t, pbits, pfxK, dir_t);
         ks_timer_end(ctx);
         SE_HIP(hipGetLastError());
-
-        // join, with a retry if the match list outgrows its first guess
-        SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, 1));
+        const bool pre = q->part_keys && q->part_pbits == pbits && q->part_K == pfxK && pbits > 0;
         u64 cap = n_q < (1u << 20) ? (1u << 20) : n_q;
         u64 n_pairs = 0;
-        for (int attempt = 0; attempt < 2; attempt++) {
-            SE_CHECK(ks_alloc(ctx, &pk0, (size_t)cap)); SE_CHECK(ks_alloc(ctx, &pv0, (size_t)cap));
-            SE_HIP(hipMemsetAsync(cursor, 0, sizeof(u64), ctx->stream));
-            ks_timer_begin(ctx, "join_buckets");
-            hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
-                               (const u32 *)qv, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds,
-                               q_lo, q_hi, (const u64 *)dir_t, pk0, pv0, cap, cursor, tbits);
-            ks_timer_end(ctx);
-            SE_HIP(hipGetLastError());
-            SE_HIP(hipMemcpyAsync(ctx->h_pin, cursor, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-            SE_HIP(hipStreamSynchronize(ctx->stream));
-            n_pairs = ctx->h_pin[0];
-            if (n_pairs <= cap) break;
-            if (attempt == 1 || n_pairs >= 0xfffffff0ULL) {
-                st = ks_fail(ctx, KS_ERR_CAPACITY, "search produced %llu matched posting pairs (cap %llu)",
-                             (unsigned long long)n_pairs, (unsigned long long)cap);
-                goto done;
+        // way 0: histogram-free bucket scatter of the sketch kernel's regions (may overflow on skewed hashes);
+        // way 1: the dense, always-correct partition
+        for (int way = (pre && pbits > 8) ? 0 : 1; way < 2; way++) {
+            u64 *qk = nullptr;
+            u32 *qv = nullptr;
+            const u64 *q_lo = nullptr, *q_hi = nullptr;
+            SE_HIP(hipMemsetAsync(cursor, 0, 2 * sizeof(u64), ctx->stream));
+            if (way == 0) {
+                const u64 per = n_q / n_buckets;
+                const u32 bcap = (u32)(per + per / 8 + 512);
+                SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_buckets * bcap));
+                SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_buckets * bcap));
+                SE_CHECK(ks_alloc(ctx, &bcur, (size_t)n_buckets));
+                SE_HIP(hipMemsetAsync(bcur, 0, (size_t)n_buckets * sizeof(u32), ctx->stream));
+                ks_rs_segments seg{q->part_len, q->part_cap, q->part_regions};
+                SE_CHECK(ks_bucket_scatter_u32(ctx, q->part_keys, q->part_vals, &seg, 8, pfxK, qk0, qv0, bcur, bcap, cursor));
+                ks_timer_begin(ctx, "bucket_dir");
+                hipLaunchKernelGGL(k_region_dir, dim3((n_buckets + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)bcur, (u64)bcap,
+                                   n_buckets, dir_q, dir_q + n_buckets);
+                ks_timer_end(ctx);
+                qk = qk0; qv = qv0; q_lo = dir_q; q_hi = dir_q + n_buckets;
+            } else if (pre && pbits <= 8) {
+                // the sketch kernel already wrote one region per bucket
+                qk = q->part_keys; qv = q->part_vals;
+                ks_timer_begin(ctx, "bucket_dir");
+                hipLaunchKernelGGL(k_region_dir, dim3((n_buckets + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)q->part_len,
+                                   q->part_cap, n_buckets, dir_q, dir_q + n_buckets);
+                ks_timer_end(ctx);
+                q_lo = dir_q; q_hi = dir_q + n_buckets;
+            } else {
+                SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qk1, (size_t)n_q));
+                SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qv1, (size_t)n_q));
+                if (pre) {
+                    // the sketch kernel did the low digit; one segmented (histogram + scan) pass on the high bits finishes
+                    const int shifts[1] = {8}; // bits [8, 16) of the join prefix
+                    ks_rs_segments seg{q->part_len, q->part_cap, q->part_regions};
+                    SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_QPART, q->part_keys, q->part_vals, qk1, qv1, qk0, qv0, n_q, shifts, 1,
+                                               &qk, &qv, &seg, pfxK));
+                } else {
+                    ks_timer_begin(ctx, "fill_query_vals");
+                    hipLaunchKernelGGL(k_fill_query_vals, dim3((q->n_seqs + 3) / 4), dim3(256), 0, ctx->stream, (const u64 *)q->d_offsets, q->n_seqs, qv0);
+                    ks_timer_end(ctx);
+                    SE_HIP(hipGetLastError());
+                    // hashes are read straight from the query sketches on the first pass (no staging copy);
+                    // qv0 holds the input qids, so the first pass lands in (qk1, qv1)
+                    int shifts[2], ns = 0;
+                    for (int sh = 0; sh < pbits; sh += 8) shifts[ns++] = sh; // digits of the join prefix, low first
+                    SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_QPART, q->d_hashes, qv0, qk1, qv1, qk0, qv0, n_q, shifts, ns, &qk, &qv,
+                                               nullptr, pfxK));
+                }
+                ks_timer_begin(ctx, "bucket_dir");
+                hipLaunchKernelGGL(k_bucket_dir, dim3((n_buckets + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)qk, n_q, pbits, pfxK, dir_q);
+                ks_timer_end(ctx);
+                q_lo = dir_q; q_hi = dir_q + 1;
             }
+            SE_HIP(hipGetLastError());
+
+            // join, with a retry if the match list outgrows its first guess
+            bool overflowed = false;
+            for (int attempt = 0; attempt < 2; attempt++) {
+                SE_CHECK(ks_alloc(ctx, &pk0, (size_t)cap)); SE_CHECK(ks_alloc(ctx, &pv0, (size_t)cap));
+                SE_HIP(hipMemsetAsync(cursor, 0, sizeof(u64), ctx->stream));
+                ks_timer_begin(ctx, "join_buckets");
+                hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
+                                   (const u32 *)qv, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds,
+                                   q_lo, q_hi, (const u64 *)dir_t, pk0, pv0, cap, cursor, tbits);
+                ks_timer_end(ctx);
+                SE_HIP(hipGetLastError());
+                SE_HIP(hipMemcpyAsync(ctx->h_pin, cursor, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+                SE_HIP(hipStreamSynchronize(ctx->stream));
+                n_pairs = ctx->h_pin[0];
+                overflowed = way == 0 && ctx->h_pin[1] != 0;
+                if (overflowed || n_pairs <= cap) break;
+                if (attempt == 1 || n_pairs >= 0xfffffff0ULL) {
+                    st = ks_fail(ctx, KS_ERR_CAPACITY, "search produced %llu matched posting pairs (cap %llu)",
+                                 (unsigned long long)n_pairs, (unsigned long long)cap);
+                    goto done;
+                }
+                ks_pool_free(ctx, pk0); ks_pool_free(ctx, pv0); pk0 = nullptr; pv0 = nullptr;
+                cap = n_pairs;
+            }
+            ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1); ks_pool_free(ctx, bcur);
+            qk0 = qk1 = nullptr; qv0 = qv1 = nullptr; bcur = nullptr;
+            if (!overflowed) {
+                H->partition_path = way == 0 ? 1 : (pre ? (pbits <= 8 ? 0 : 2) : 3);
+                break;
+            }
+            // a bucket overflowed (skewed hashes): drop the partial result and partition the dense way
             ks_pool_free(ctx, pk0); ks_pool_free(ctx, pv0); pk0 = nullptr; pv0 = nullptr;
-            cap = n_pairs;
         }
-        ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
-        qk0 = qk1 = nullptr; qv0 = qv1 = nullptr;
         H->n_pair_instances = n_pairs;
         if (n_pairs == 0) {
             SE_CHECK(ks_alloc(ctx, &H->d_qid, 1)); SE_CHECK(ks_alloc(ctx, &H->d_tid, 1));
@@ -403,7 +438,7 @@ done:
     ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
     ks_pool_free(ctx, pk0); ks_pool_free(ctx, pk1); ks_pool_free(ctx, pv0); ks_pool_free(ctx, pv1);
     ks_pool_free(ctx, heads); ks_pool_free(ctx, d_nrows); ks_pool_free(ctx, row_start); ks_pool_free(ctx, cursor);
-    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, dir_t);
+    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, dir_t); ks_pool_free(ctx, bcur);
     if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_hits_free(H); return st; }
     *out = H;
     return KS_OK;

@@ -74,13 +74,13 @@ struct sk_args {
     unsigned long long *tile_status; // [n_tiles] (flag << 62) | value; flag 1 = tile aggregate, 2 = inclusive prefix
     u32 *ticket;    // [0] dynamic tile id, [1] status bits: 1 = a bounded spin expired, 2 = postings not emitted for some tile
     u32 n_tiles;
-    // optional: postings (hash, sequence) partitioned on hash bits [part_shift, part_shift + 8) into 256 fixed-capacity
+    // optional: postings (hash, sequence) partitioned on the low 8 bits of the join prefix into <= 256 fixed-capacity
     // regions, written while the vector ALU is the bottleneck — the query side's first partition pass of ks_search
     u64 *part_keys;   // [256 * part_cap] or NULL
     u32 *part_vals;
     u32 *part_cursor; // [256] records placed per region so far
     u64 part_cap;
-    u32 part_shift, part_mask;
+    u32 part_K, part_mask; // region = ks_join_prefix(h, part_K) & part_mask
 };
 
 #define SK_FLAG_AGG (1ULL << 62)
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
 #pragma unroll
             for (int i = 0; i < SK_E; i++)
                 if (pr[i] != 0xffffffffu && (pr[i] & 1u))
-                    ab[i] = atomicAdd(&bins[(u32)(h[i] >> A.part_shift) & A.part_mask], 1u); // rank inside (tile, digit)
+                    ab[i] = atomicAdd(&bins[ks_join_prefix(h[i], A.part_K) & A.part_mask], 1u); // rank inside (tile, digit)
             __syncthreads();
             {
                 const u32 c = tid < 256 ? bins[tid] : 0;
@@ -559,14 +559,14 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
 #pragma unroll
             for (int i = 0; i < SK_E; i++)
                 if (pr[i] != 0xffffffffu && (pr[i] & 1u)) {
-                    const u32 pos = bins[(u32)(h[i] >> A.part_shift) & A.part_mask] + ab[i];
+                    const u32 pos = bins[ks_join_prefix(h[i], A.part_K) & A.part_mask] + ab[i];
                     tmp[pos] = h[i];
                     qrel[pos] = (u16)SK_BO_S(bo[i]);
                 }
             __syncthreads();
             for (u32 i = tid; i < n_distinct; i += SK_THREADS) {
                 const u64 hh = tmp[i];
-                const u32 dg = (u32)(hh >> A.part_shift) & A.part_mask;
+                const u32 dg = ks_join_prefix(hh, A.part_K) & A.part_mask;
                 const u64 slot = (u64)gbase[dg] + (i - bins[dg]);
                 if (slot < A.part_cap) {
                     A.part_keys[(u64)dg * A.part_cap + slot] = hh;
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u64 *offs, const u64 *csr, const u64 *lg_hash,
                                                     const u32 *lg_abund, u64 *hashes, u32 *abunds, u64 *part_keys,
-                                                    u32 *part_vals, u32 *part_cursor, u64 part_cap, u32 part_shift,
+                                                    u32 *part_vals, u32 *part_cursor, u64 part_cap, u32 part_K,
                                                     u32 part_mask, u32 *status) {
     const u32 s = ids[blockIdx.x];
     const u64 dst = csr[s], n = csr[s + 1] - dst, src = offs[s];
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u64 *o
         hashes[dst + i] = h;
         abunds[dst + i] = lg_abund[src + i];
         if (part_keys) { // long sequences are rare: one device atomic per posting is fine here
-            const u32 dg = (u32)(h >> part_shift) & part_mask;
+            const u32 dg = ks_join_prefix(h, part_K) & part_mask;
             const u64 slot = atomicAdd(&part_cursor[dg], 1u);
             if (slot < part_cap) {
                 part_keys[(u64)dg * part_cap + slot] = h;
@@ -861,7 +861,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             // first partition digit: the low 8 bits of the join's hash prefix (the whole prefix if it is <= 8 bits)
             const int dbits = part_pbits < 8 ? part_pbits : 8;
             S->part_pbits = part_pbits;
-            S->part_shift = 64 - part_pbits;
+            S->part_K = ks_join_prefix_mul(part_pbits, A.max_hash);
             S->part_regions = 1u << dbits;
             const u64 per = S->n_windows / S->part_regions;
             u64 cap = per + per / 4 + 8192;                 // uniform hashes fill regions evenly; skew -> fallback
@@ -872,7 +872,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             SK_CHECK(ks_alloc(ctx, &S->part_len, 256));
             SK_HIPCHECK(hipMemsetAsync(S->part_len, 0, 256 * sizeof(u32), ctx->stream));
             A.part_keys = S->part_keys; A.part_vals = S->part_vals; A.part_cursor = S->part_len; A.part_cap = cap;
-            A.part_shift = (u32)S->part_shift; A.part_mask = S->part_regions - 1;
+            A.part_K = S->part_K; A.part_mask = S->part_regions - 1;
         }
 
         // ---- medium / long sequences first: their unique counts feed the tile kernel's CSR prefix
@@ -948,7 +948,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             ks_timer_begin(ctx, "place_long");
             hipLaunchKernelGGL(k_place_long, dim3((u32)n_long), dim3(256), 0, ctx->stream, (const u32 *)long_ids, d_offs,
                                (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds,
-                               A.part_keys, A.part_vals, A.part_cursor, A.part_cap, A.part_shift, A.part_mask, ticket);
+                               A.part_keys, A.part_vals, A.part_cursor, A.part_cap, A.part_K, A.part_mask, ticket);
             ks_timer_end(ctx);
         }
         SK_HIPCHECK(hipGetLastError());

@@ -310,6 +310,11 @@ class Hits(_Owned):
     def n_pair_instances(self) -> int:
         return int(self._ctx._L.ks_hits_n_pair_instances(self._h))
 
+    @property
+    def partition_path(self) -> int:
+        """0 sketch regions == buckets, 1 regions + bucket scatter, 2 regions + dense pass, 3 dense from the CSR."""
+        return int(self._ctx._L.ks_hits_partition_path(self._h))
+
     def to_host(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
         n = self.count
         qid = np.zeros(n, np.uint32); tid = np.zeros(n, np.uint32)

@@ -285,7 +285,9 @@ def test_presorted_query_postings_equal_plain_search(ctx, k, scaled, mol, nt, nq
     assert Q.has_postings
     for g, w in zip(Q.to_host(), plain_Q.to_host()):
         assert np.array_equal(g, w)
-    got = ctx.search(ix, Q).to_host()
+    H = ctx.search(ix, Q)
+    assert H.partition_path == (0 if ix.n_postings <= 3072 * 256 else 1)
+    got = H.to_host()
     assert len(want[0]) > 0
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
@@ -317,3 +319,24 @@ def test_presorted_postings_fall_back_on_skewed_hashes(ctx):
     qid, tid, isect, nw = ctx.search(ix, Q).to_host()
     self_hits = tid == 7
     assert self_hits.sum() == 20000 and np.all(isect[self_hits] == n1)
+
+
+def test_bucket_scatter_overflow_falls_back_to_dense_partition(ctx):
+    """1500 copies of one protein among normal queries: the sketch kernel's 256 regions hold, but the join buckets of
+    the ~290 repeated hashes overflow their fixed capacity -> ks_search must redo the partition the dense way."""
+    t_res, t_off = synth.proteome(30000, stream=97)
+    one = bytes(t_res[int(t_off[11]):int(t_off[12])])
+    q_norm = synth.queries(500, t_res, t_off, stream=98)
+    seqs = [bytes(q_norm[0][int(q_norm[1][i]):int(q_norm[1][i + 1])]) for i in range(500)] + [one] * 1500
+    q_res, q_off = ks.pack(seqs)
+    ix = ctx.index_build(ctx.sketch_batch(t_res, t_off, 10, 1, "protein"))
+    want = ctx.search(ix, ctx.sketch_batch(q_res, q_off, 10, 1, "protein")).to_host()
+    d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
+    Q = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
+    assert Q.has_postings
+    H = ctx.search(ix, Q)
+    assert H.partition_path == 2  # bucket scatter overflowed, dense pass over the regions took over
+    got = H.to_host()
+    assert (want[1] == 11).sum() >= 1500
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
