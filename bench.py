@@ -70,38 +70,40 @@ def main():
     import kmerseek_amd as ks
     from kmerseek_amd import synth
 
+    from kmerseek_amd import dist as ksd
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # KS_BENCH_REHEARSE=1: run the N-rank path on ONE GPU (all ranks on device 0, gloo instead of RCCL) to rehearse
+    # the launcher / collective plumbing on a single-GPU box; numbers from such a run mean nothing.
+    rehearse = os.environ.get("KS_BENCH_REHEARSE") == "1"
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = torch.device("cpu") if rehearse else dev  # where collective buffers live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         dist.barrier()
 
     k, scaled, mol = args.ksize, args.scaled, args.moltype
 
-    # ---- synthetic inputs (seeded).  Index: rank 0 generates, broadcast over RCCL/xGMI.
+    # ---- synthetic inputs (seeded).  Index: rank 0 generates the residues, broadcast over RCCL/xGMI,
+    # every rank sketches + sorts them locally (cheaper than shipping 3.5 GB of postings).
     t0 = time.time()
     if rank == 0:
         t_res_h, t_off_h = synth.proteome(args.targets, stream=0)
-        meta = torch.tensor([len(t_res_h), len(t_off_h)], dtype=torch.int64, device=dev)
     else:
-        meta = torch.zeros(2, dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.broadcast(meta, 0)
-    n_t_res, n_t_off = int(meta[0]), int(meta[1])
-    if rank == 0:
-        t_res = torch.from_numpy(t_res_h).to(dev)
-        t_off = torch.from_numpy(t_off_h.view(np.int64)).to(dev)
-    else:
-        t_res = torch.empty(n_t_res, dtype=torch.uint8, device=dev)
-        t_off = torch.empty(n_t_off, dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.broadcast(t_res, 0)
-        dist.broadcast(t_off, 0)
+        t_res_h = t_off_h = None
+    t_res, t_off = ksd.broadcast_batch(t_res_h, t_off_h, src=0, device=cdev)
+    if rank != 0:
         t_res_h = t_res.cpu().numpy()
         t_off_h = t_off.cpu().numpy().view(np.uint64)
+    t_res, t_off = t_res.to(dev), t_off.to(dev)
+    n_t_res = int(t_res.numel())
     q_res_h, q_off_h = synth.queries(args.queries, t_res_h, t_off_h, stream=1000 + rank)
     q_res = torch.from_numpy(q_res_h).to(dev)
     q_off = torch.from_numpy(q_off_h.view(np.int64)).to(dev)
@@ -111,7 +113,7 @@ def main():
     gen_s = time.time() - t0
 
     stream = torch.cuda.current_stream(dev)
-    ctx = ks.Context(local_rank, stream=stream.cuda_stream)
+    ctx = ks.Context(dev_index, stream=stream.cuda_stream)
 
     # ---- index build (once, untimed region; reported)
     torch.cuda.synchronize(dev)
@@ -162,8 +164,8 @@ def main():
     ctx.timing_enable(False)
     timing_all = {k_: (n_ / 2, ms_ / 2) for k_, (n_, ms_) in ctx.timing().items()}
 
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([q_windows, args.queries, stats[1]], dtype=torch.int64, device=dev)
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    tot = torch.tensor([q_windows, args.queries, stats[1]], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -225,14 +227,14 @@ def main():
         t_o, t_m, t_a = T.to_host()
         ns = args.cpu_sample_queries
         if ns <= 0:
-            # pilot: time one query per core against the full index, then size the sample for ~12 s
+            # pilot: time one query per core against the full index, then size the sample for ~20 s
             pidx = np.linspace(0, args.queries - 1, cores).astype(np.int64)
             p_res, p_off = oracle.pack([bytes(q_res_h[int(q_off_h[i]):int(q_off_h[i + 1])]) for i in pidx])
             po, pm, _ = oracle.sketch_batch(p_res, p_off, k, scaled, mol, n_threads=cores)
             c0 = time.perf_counter()
             oracle.manysearch(po, pm, t_o, t_m, t_a, n_threads=cores)
             pilot = max(time.perf_counter() - c0, 1e-3)
-            ns = int(max(cores, min(args.queries, cores * 12.0 / pilot)))
+            ns = int(max(cores, min(args.queries, cores * 20.0 / pilot)))
             ns = max(cores, (ns // cores) * cores)
         ns = min(ns, args.queries)
         # sample = evenly spaced queries (mix of related and independent)

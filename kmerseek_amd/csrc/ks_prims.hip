@@ -226,6 +226,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
     u64 tile_base;
     u32 nvalid;
     rs_tile_geom(n, seg_len, seg_cap, tiles_per_seg, tile_base, nvalid);
+    if (BUCKETS && nvalid == 0) return; // tile beyond the region's fill (uniform per block; nothing to reserve)
     const u32 wloc = wave * (64 * RS_IPT); // this wave's first record inside the tile
     u64 key[RS_IPT];
     V val[RS_IPT];

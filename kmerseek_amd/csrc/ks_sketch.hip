@@ -863,7 +863,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             S->part_pbits = part_pbits;
             S->part_K = ks_join_prefix_mul(part_pbits, A.max_hash);
             S->part_regions = 1u << dbits;
-            const u64 per = S->n_windows / S->part_regions;
+            const u64 per = S->n_windows / p->scaled / S->part_regions + 1; // FracMinHash keeps ~1/scaled of the windows
             u64 cap = per + per / 4 + 8192;                 // uniform hashes fill regions evenly; skew -> fallback
             cap = (cap + 8191) / 8192 * 8192;
             S->part_cap = cap;
