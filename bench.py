@@ -258,7 +258,9 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{args.queries // 1000}k query proteins per GPU vs {args.targets // 1000}k-protein index, "
-                               f"{mol} k={k} scaled={scaled} (BASELINE configs[3] shape: 1M-vs-1M k=10 scaled=1)",
+                               f"{mol} k={k} scaled={scaled}" + (" (BASELINE configs[3]: 1M-vs-1M, k=10 scaled=1 protein)"
+                                                                if (args.queries, args.targets, k, scaled, mol) ==
+                                                                (1_000_000, 1_000_000, 10, 1, "protein") else ""),
                    "queries_per_gpu": args.queries, "targets": args.targets, "ksize": k, "scaled": scaled,
                    "moltype": mol, "parallelism": f"queries sharded x{args.gpus}, index replicated"},
         "query_proteins_per_s": all_queries * args.steps / elapsed,

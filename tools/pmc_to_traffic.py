@@ -15,10 +15,11 @@ import sys
 
 NAMES = {  # profiler kernel name prefix -> library timing name
     "void k_sketch_tiles<0>": "sketch_tiles",
-    "void k_radix_scatter<unsigned int, 1>": "radix_scatter.qpart",
+    "void k_radix_scatter<unsigned int, 1, true>": "radix_scatter.qpart",
+    "void k_radix_scatter<unsigned int, 1, false>": "radix_scatter.qpart.dense",
     "void k_radix_hist<1>": "radix_hist.qpart",
     "k_join_buckets": "join_buckets",
-    "void k_radix_scatter<unsigned long, 0>": "radix_scatter.index",
+    "void k_radix_scatter<unsigned long, 0, false>": "radix_scatter.index",
 }
 
 
@@ -37,7 +38,9 @@ def main():
     for kname, rows in f.items():
         for pref, lib in NAMES.items():
             if kname.startswith(pref):
-                g = max(x[1] for x in rows)  # the full-size launches (largest grid)
+                # the per-step (query-side) launches: the grid size that occurs most often (the one-off index build differs)
+                grids = collections.Counter(x[1] for x in rows)
+                g = max(grids, key=lambda v: (grids[v], v))
                 fetch = [x[0] for x in rows if x[1] == g]
                 write = [x[0] for x in w.get(kname, []) if x[1] == g]
                 fb = 2.0 * 1024.0 * sum(fetch) / len(fetch)
