@@ -209,3 +209,120 @@ def do_manysearch(query_sig: str, target_sig: str, output: str, ksize: int, scal
     finally:
         if own:
             ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# k-mer tables and alignment stitching  — src/python/kmerseek/sig2kmer.py:186-219, search.py:37-121,195-276
+# ---------------------------------------------------------------------------------------------------------
+_DAYHOFF = {**{c: "a" for c in "C"}, **{c: "b" for c in "AGPST"}, **{c: "c" for c in "DENQ"}, **{c: "d" for c in "HKR"},
+            **{c: "e" for c in "ILMV"}, **{c: "f" for c in "FWY"}}
+_HP = {**{c: "h" for c in "AFGILMPVWY"}, **{c: "p" for c in "NCSTDERHKQ"}}
+
+
+def encode_kmer(kmer: str, moltype: str) -> str:
+    """The `encoded` column: residue-wise re-encode (sig2kmer.py:40-58 / src/rust/encoding.rs:67-105)."""
+    if moltype in ("protein", "raw"):
+        return kmer
+    table = _DAYHOFF if moltype == "dayhoff" else _HP
+    return "".join(table.get(c, "X") for c in kmer)
+
+
+def extract_kmers(ctx: Context, records: Sequence[Tuple[str, bytes]], ksize: int, scaled: int, moltype: str,
+                  sequence_file: str = "") -> List[dict]:
+    """Rows of the reference's k-mer table (sequence_file, sequence_name, kmer, hashval, encoded, start): one per window
+    whose hash is in the sequence's sketch.  Positions and hashes come from the GPU (ks_kmer_positions)."""
+    from .engine import pack
+    res, offs = pack([s for _, s in records])
+    seq_i, start, hashes = ctx.kmer_positions(res, offs, ksize, scaled, moltype)
+    rows = []
+    for s, st, h in zip(seq_i.tolist(), start.tolist(), hashes.tolist()):
+        name, seq = records[s]
+        kmer = seq[st:st + ksize].decode().upper()
+        rows.append({"sequence_file": sequence_file, "sequence_name": name, "kmer": kmer, "hashval": h,
+                     "encoded": encode_kmer(kmer, moltype), "start": st})
+    return rows
+
+
+def write_kmers_parquet(rows: List[dict], path: str) -> None:
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    cols = ["sequence_file", "sequence_name", "kmer", "hashval", "encoded", "start"]
+    tab = pa.table({
+        "sequence_file": pa.array([r["sequence_file"] for r in rows], pa.string()),
+        "sequence_name": pa.array([r["sequence_name"] for r in rows], pa.string()),
+        "kmer": pa.array([r["kmer"] for r in rows], pa.string()),
+        "hashval": pa.array([r["hashval"] for r in rows], pa.uint64()),
+        "encoded": pa.array([r["encoded"] for r in rows], pa.string()),
+        "start": pa.array([r["start"] for r in rows], pa.uint32()),
+    })
+    assert tab.column_names == cols
+    pq.write_table(tab, path)
+
+
+def single_stitch_together_kmers(kmers: Sequence[str], i_kmers: Sequence[int]) -> str:
+    """search.py:37-60, quirks included (a zero step re-appends the whole k-mer: kmer[-0:])."""
+    stitched = ""
+    prev = 0
+    for i, (pos, kmer) in enumerate(zip(i_kmers, kmers)):
+        if i == 0:
+            stitched = kmer
+        else:
+            step = pos - prev
+            stitched += kmer[-step:]
+        prev = pos
+    return stitched
+
+
+def stitch_hits(query_kmers: List[dict], target_kmers: List[dict], hit_pairs: Sequence[Tuple[str, str]]) -> List[dict]:
+    """search.py:195-240: join query and target k-mers on (encoded, hashval), keep the pairs that are search hits,
+    group by match_name, stitch overlapping k-mers into one aligned region per match; rows sorted by (query_start, query_end)."""
+    by_key = {}
+    for r in target_kmers:
+        by_key.setdefault((r["encoded"], r["hashval"]), []).append(r)
+    hitset = set(hit_pairs)
+    groups = {}
+    for q in query_kmers:
+        for t in by_key.get((q["encoded"], q["hashval"]), ()):
+            if (q["sequence_name"], t["sequence_name"]) in hitset:
+                groups.setdefault(t["sequence_name"], []).append(
+                    {"query_name": q["sequence_name"], "match_name": t["sequence_name"], "kmer_query": q["kmer"],
+                     "kmer_match": t["kmer"], "encoded": q["encoded"], "start_query": q["start"], "start_match": t["start"]})
+    out = []
+    for match_name, rows in groups.items():
+        rows.sort(key=lambda r: r["start_query"])
+        # search.py:79-81: the query k-mers are stitched with the MATCH positions (as the reference does)
+        query = single_stitch_together_kmers([r["kmer_query"] for r in rows], [r["start_match"] for r in rows])
+        alpha = single_stitch_together_kmers([r["encoded"] for r in rows], [r["start_query"] for r in rows])
+        match = single_stitch_together_kmers([r["kmer_match"] for r in rows], [r["start_match"] for r in rows])
+        assert len(query) == len(alpha) == len(match)
+        length = len(query)
+        ms = min(r["start_match"] for r in rows)
+        qs = min(r["start_query"] for r in rows)
+        qn = rows[0]["query_name"]
+        out.append({"match_name": match_name, "query_name": qn, "query_start": qs, "query_end": qs + length,
+                    "query": query, "match_start": ms, "match_end": ms + length, "match": match, "encoded": alpha,
+                    "length": length,
+                    "to_print": f"\n---\nQuery Name: {qn}\nMatch Name: {match_name}\nquery: {query} ({qs}-{qs + length})\n"
+                                f"alpha: {alpha}\nmatch: {match} ({ms}-{ms + length})"})
+    out.sort(key=lambda r: (r["query_start"], r["query_end"]))
+    return out
+
+
+def search_extract_kmers(query_fasta: str, target_fasta: str, ksize: int, scaled: int, moltype: str,
+                         ctx: Optional[Context] = None) -> List[dict]:
+    """`kmerseek search --extract-kmers QUERY TARGET` end to end: sketch both, search, k-mer tables, stitch."""
+    own = ctx is None
+    ctx = ctx or Context(0)
+    try:
+        from .engine import pack
+        q_recs, t_recs = read_fasta(query_fasta), read_fasta(target_fasta)
+        Q = ctx.sketch_batch(*pack([s for _, s in q_recs]), ksize, scaled, moltype)
+        T = ctx.sketch_batch(*pack([s for _, s in t_recs]), ksize, scaled, moltype)
+        qid, tid, _, _ = ctx.search(ctx.index_build(T), Q).to_host()
+        pairs = [(q_recs[q][0], t_recs[t][0]) for q, t in zip(qid.tolist(), tid.tolist())]
+        qk = extract_kmers(ctx, q_recs, ksize, scaled, moltype, query_fasta)
+        tk = extract_kmers(ctx, t_recs, ksize, scaled, moltype, target_fasta)
+        return stitch_hits(qk, tk, pairs)
+    finally:
+        if own:
+            ctx.close()

@@ -234,3 +234,40 @@ def test_manysearch_csv_equals_expected(tmp_path, search_expected):
                 assert g[col] == w[col], col
             else:
                 assert math.isclose(float(g[col]), float(w[col]), rel_tol=1e-12, abs_tol=1e-15), (col, g[col], w[col])
+
+
+# tests/test_index.py:61-71, tests/test_entity.py:48-59 (k-mer table equals the golden parquet, shape (1712, 5))
+@pytest.mark.parametrize("key,ksize", [("hp.k24.scaled5", 24), ("hp.k16.scaled5", 16)])
+def test_kmer_table_equals_golden(tmp_path, golden_kmer_tables, bcl2_records, key, ksize):
+    with ks.Context(0) as ctx:
+        rows = wire.extract_kmers(ctx, bcl2_records, ksize, 5, "hp", "bcl2.fasta.gz")
+    gold = golden_kmer_tables[key]
+    assert len(rows) == gold["n_rows"]
+    got = {}
+    for r in rows:
+        got.setdefault(r["sequence_name"], []).append([r["start"], r["kmer"], r["encoded"], r["hashval"]])
+    assert {n: sorted(v) for n, v in got.items()} == {n: sorted(v) for n, v in gold["rows"].items()}
+    out = tmp_path / "kmers.pq"
+    wire.write_kmers_parquet(rows, str(out))
+    import pyarrow.parquet as pq
+    t = pq.read_table(out)
+    assert t.num_rows == gold["n_rows"] and t.column_names == ["sequence_file", "sequence_name", "kmer", "hashval", "encoded", "start"]
+    if ksize == 24:
+        assert t.num_rows == 1712
+
+
+# tests/test_search.py:63-138 (search --extract-kmers: stitched rows and the printed alignment blocks)
+def test_search_extract_kmers_equals_expected(tmp_path, search_expected):
+    rows = wire.search_extract_kmers(os.path.join(GOLDEN, "ced9.fasta"), os.path.join(GOLDEN, BCL2), 16, 5, "hp")
+    exp = sorted(search_expected["stitched_rows"], key=lambda r: r["match_name"])
+    got = sorted(rows, key=lambda r: r["match_name"])
+    assert len(got) == len(exp) == 5
+    for g, w in zip(got, exp):
+        for col in search_expected["stitched_columns"]:
+            assert str(g[col]) == str(w[col]), (col, g[col], w[col])
+    printed = "\n".join(r["to_print"] for r in rows)
+    assert "query: MSIGESIDGKINDWEEPGIVGVVVCGRMMFSLK (59-92)" in printed
+    assert "alpha: hphhpphphphpphpphhhhhhhhphphhhphp" in printed
+    assert "match: HQQEQEAEGVAAPADP (42-58)" in printed
+    # rows come out sorted by (query_start, query_end), as the reference prints them
+    assert [r["query_start"] for r in rows] == sorted(r["query_start"] for r in rows)
