@@ -188,7 +188,7 @@ def main():
         "sketch_tiles": n_q_res + 12 * n_q_hashes + 8 * args.queries,
         "sketch_gather": 24 * n_q_hashes,
         # one partition pass moves each (hash u64, qid u32) posting once in, once out
-        "radix_scatter.qpart": 24 * n_q_hashes,
+        "bucket_scatter": 24 * n_q_hashes,
         "radix_hist.qpart": 8 * n_q_hashes,
         # join: 12 B per query posting + 12 B per index posting read once + 16 B per emitted pair
         "join_buckets": 12 * n_q_hashes + 12 * n_t_postings + 16 * n_pairs,

@@ -200,16 +200,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 
 // ranks computed per wave with ballot-matching + per-wave digit counters preserve input order.
 // Records are staged through ONE LDS buffer in local digit order (keys first, then values), so each
 // digit leaves the tile as a contiguous run of full cache lines.
-// BUCKETS = true: the last partition pass of a search.  The input is segmented by the LOW digit (region r), this pass
-// splits on the HIGH digit d, and the output is not a dense sorted array but 2^pbits fixed-capacity buckets
-// (bucket (d << 8 | r) at bucket * bcap): each tile reserves its slice of a bucket with one atomic per digit, so
-// there is no histogram pass and no scan (order inside a bucket is irrelevant to the join).  A bucket that would
-// overflow raises status[1] and the host redoes the pass the dense way.
-template <typename V, int TAG, bool BUCKETS>
+template <typename V, int TAG>
 __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64 *kin, const V *vin, u64 *kout, V *vout,
                                                               const u32 *goffs, u64 n, int shift, u32 nblocks,
-                                                              const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg,
-                                                              u32 *bcur, u32 bcap, unsigned long long *status, u32 pfxK) {
+                                                              const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg, u32 pfxK) {
     __shared__ u32 wcnt[RS_WAVES][256];
     __shared__ u32 dstart[256];
     __shared__ u32 gbase[256];
@@ -219,14 +213,13 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 256) {
         for (int w = 0; w < RS_WAVES; w++) wcnt[w][tid] = 0;
-        if (!BUCKETS) gbase[tid] = goffs[(u64)tid * nblocks + blockIdx.x];
+        gbase[tid] = goffs[(u64)tid * nblocks + blockIdx.x];
     }
     __syncthreads();
 
     u64 tile_base;
     u32 nvalid;
     rs_tile_geom(n, seg_len, seg_cap, tiles_per_seg, tile_base, nvalid);
-    if (BUCKETS && nvalid == 0) return; // tile beyond the region's fill (uniform per block; nothing to reserve)
     const u32 wloc = wave * (64 * RS_IPT); // this wave's first record inside the tile
     u64 key[RS_IPT];
     V val[RS_IPT];
@@ -270,17 +263,6 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
         u32 ds = ks_block_excl_scan(tot, scan_smem, &total);
         if (tid < 256) {
             dstart[tid] = ds;
-            if (BUCKETS) { // reserve [base, base + tot) of bucket (digit << 8 | region); invalid tail records sit in digit 255
-                u32 mine = tot;
-                if (tid == 255) mine -= RS_TILE - nvalid;
-                u32 base = 0;
-                if (mine) {
-                    const u32 bucket = (tid << 8) | (blockIdx.x / tiles_per_seg);
-                    base = atomicAdd(&bcur[bucket], mine);
-                    if (base + mine > bcap) atomicOr(&status[1], 1ULL);
-                }
-                gbase[tid] = base;
-            }
 #pragma unroll
             for (int w = 0; w < RS_WAVES; w++) { wcnt[w][tid] = ds; ds += c[w]; }
         }
@@ -301,13 +283,8 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
         if (p < nvalid) {
             u64 k = stage[p];
             u32 d = ks_rs_digit(k, shift, pfxK);
-            if (BUCKETS) {
-                const u32 slot = gbase[d] + (p - dstart[d]);
-                if (slot < bcap) gdst[i] = (u64)((d << 8) | (blockIdx.x / tiles_per_seg)) * bcap + slot;
-            } else {
-                gdst[i] = (u64)gbase[d] + (p - dstart[d]);
-            }
-            if (gdst[i] != ~0ULL) kout[gdst[i]] = k;
+            gdst[i] = (u64)gbase[d] + (p - dstart[d]);
+            kout[gdst[i]] = k;
         }
     }
     __syncthreads();
@@ -320,6 +297,98 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
         u32 p = (u32)i * RS_THREADS + tid;
         if (gdst[i] != ~0ULL) vout[gdst[i]] = vstage[p];
     }
+}
+
+// The last partition pass of a search: segmented postings (region r = low digit of the join prefix) -> 2^pbits
+// fixed-capacity buckets (bucket (d << 8 | r) at bucket * bcap, d = high digit).  Each tile reserves its slice of a
+// bucket with one global atomic per digit, so there is no histogram pass and no scan; order inside a bucket is
+// irrelevant to the join, so the rank of a record inside its (tile, digit) group is just the return value of one LDS
+// atomic — no ballot matching, no per-wave counters.  A bucket that would overflow raises status[1] and the host
+// redoes the pass the dense (stable, histogrammed) way.
+__global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout,
+                                                                        int shift, const u32 *seg_len, u64 seg_cap,
+                                                                        u32 tiles_per_seg, u32 *bcur, u32 bcap,
+                                                                        unsigned long long *status, u32 pfxK) {
+    __shared__ u32 cnt[256];
+    __shared__ u32 dstart[256];
+    __shared__ u32 gbase[256];
+    __shared__ u32 scan_smem[RS_WAVES + 1];
+    __shared__ __attribute__((aligned(16))) u64 stage[RS_TILE];
+
+    const u32 tid = threadIdx.x;
+    u64 tile_base;
+    u32 nvalid;
+    rs_tile_geom(0, seg_len, seg_cap, tiles_per_seg, tile_base, nvalid);
+    if (nvalid == 0) return; // tile beyond the region's fill (uniform per block)
+    const u32 region = blockIdx.x / tiles_per_seg;
+    if (tid < 256) cnt[tid] = 0;
+    u64 key[RS_IPT];
+    u32 val[RS_IPT];
+    u32 rank[RS_IPT]; // (digit << 16) | rank within (tile, digit); 0xffffffff = no record
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++) {
+        const u32 li = (u32)r * RS_THREADS + tid;
+        const bool valid = li < nvalid;
+        key[r] = valid ? kin[tile_base + li] : 0ULL;
+        val[r] = valid ? vin[tile_base + li] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++) {
+        const u32 li = (u32)r * RS_THREADS + tid;
+        rank[r] = 0xffffffffu;
+        if (li < nvalid) {
+            const u32 d = ks_rs_digit(key[r], shift, pfxK);
+            rank[r] = (d << 16) | atomicAdd(&cnt[d], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        const u32 c = tid < 256 ? cnt[tid] : 0u;
+        u32 total;
+        const u32 ds = ks_block_excl_scan(c, scan_smem, &total);
+        if (tid < 256) {
+            dstart[tid] = ds;
+            u32 base = 0;
+            if (c) {
+                base = atomicAdd(&bcur[(tid << 8) | region], c);
+                if (base + c > bcap) atomicOr(&status[1], 1ULL);
+            }
+            gbase[tid] = base;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++)
+        if (rank[r] != 0xffffffffu) {
+            rank[r] = dstart[rank[r] >> 16] + (rank[r] & 0xffffu);
+            stage[rank[r]] = key[r];
+        }
+    __syncthreads();
+    u64 gdst[RS_IPT]; // global destination of local slot i*RS_THREADS + tid
+#pragma unroll
+    for (int i = 0; i < RS_IPT; i++) {
+        const u32 p = (u32)i * RS_THREADS + tid;
+        gdst[i] = ~0ULL;
+        if (p < nvalid) {
+            const u64 k = stage[p];
+            const u32 d = ks_rs_digit(k, shift, pfxK);
+            const u32 slot = gbase[d] + (p - dstart[d]);
+            if (slot < bcap) {
+                gdst[i] = (u64)((d << 8) | region) * bcap + slot;
+                kout[gdst[i]] = k;
+            }
+        }
+    }
+    __syncthreads();
+    u32 *vstage = (u32 *)stage;
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++)
+        if (rank[r] != 0xffffffffu) vstage[rank[r]] = val[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_IPT; i++)
+        if (gdst[i] != ~0ULL) vout[gdst[i]] = vstage[(u32)i * RS_THREADS + tid];
 }
 
 static const char *const rs_tag_names[3] = {"index", "qpart", "pairs"};
@@ -358,9 +427,8 @@ static int radix_sort_tagged(ks_ctx *ctx, const u64 *keys_in, const V *vals_in, 
         st = ks_scan_u32_inplace(ctx, hist, (u64)256 * nblocks, nullptr);
         if (st != KS_OK) break;
         ks_timer_begin(ctx, nm_scat.c_str());
-        hipLaunchKernelGGL((k_radix_scatter<V, TAG, false>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, kin, vin, kout, vout,
-                           (const u32 *)hist, n, shifts[i], nblocks, s_len, s_cap, tiles_per_seg, (u32 *)nullptr, 0u,
-                           (unsigned long long *)nullptr, pfxK);
+        hipLaunchKernelGGL((k_radix_scatter<V, TAG>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, kin, vin, kout, vout,
+                           (const u32 *)hist, n, shifts[i], nblocks, s_len, s_cap, tiles_per_seg, pfxK);
         ks_timer_end(ctx);
         if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "radix sort launch failed");
         kin = kout;
@@ -390,10 +458,9 @@ int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, c
                           u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status) {
     const u32 tiles_per_seg = (u32)((seg->cap + RS_TILE - 1) / RS_TILE);
     const u32 nblocks = seg->regions * tiles_per_seg;
-    ks_timer_begin(ctx, "radix_scatter.qpart");
-    hipLaunchKernelGGL((k_radix_scatter<u32, KS_SORT_QPART, true>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in,
-                       bkeys, bvals, (const u32 *)nullptr, (u64)0, shift, nblocks, seg->len, seg->cap, tiles_per_seg, bcur, bcap,
-                       status, pfxK);
+    ks_timer_begin(ctx, "bucket_scatter");
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in, bkeys, bvals, shift,
+                       seg->len, seg->cap, tiles_per_seg, bcur, bcap, status, pfxK);
     ks_timer_end(ctx);
     KS_HIP(ctx, hipGetLastError());
     return KS_OK;

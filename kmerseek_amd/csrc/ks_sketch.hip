@@ -19,17 +19,24 @@
 //     bucket: the first arrival is the representative and carries the abundance.
 //   * Representatives are compacted through LDS and leave as one contiguous run per tile; a per-sequence
 //     count + scan + gather builds the final CSR.
-//   * Sequences longer than LS_MAX but shorter than a tile ("medium") get a tile of their own in a second
-//     launch of the same kernel; longer ones take the same algorithm with its arrays in a global scratch
-//     slab (k_sketch_long), one workgroup per sequence.
+//   * A sequence that starts inside a tile's residue range but does not END inside the tile's LDS window (at most
+//     one per tile, the last) is deferred: if it fits a tile on its own ("medium") it gets one in a second launch of
+//     the same kernel; longer ones take the same algorithm with its arrays in a global scratch slab (k_sketch_long),
+//     one workgroup per sequence.
 #include "ks_device.h"
 
 #define SK_THREADS 512
 #define SK_E 8
 #define SK_TILE (SK_THREADS * SK_E) // 4096 LDS positions
-#define SK_LS_MAX 1536              // longest sequence a shared (multi-sequence) tile takes
 #define SK_MED_MAX (SK_TILE - 16)   // longest sequence that still fits one tile on its own ("medium")
-#define SK_R (SK_TILE - SK_LS_MAX - 16)
+// Tile t takes the sequences that START in residues [t * R, (t+1) * R) and stages SK_TILE bytes from t * R: a larger
+// stride R fills more of the tile's positions with windows but defers more sequences (one that starts at local position
+// p with length L is deferred when p + L > SK_MED_MAX, i.e. with probability ~ E[max(0, L - (SK_MED_MAX - R))] / R).
+// R is chosen per batch from these candidates (all multiples of 16) by a measured cost model: a shared tile avoided
+// saves ~26 ns, a deferred sequence costs ~45 ns (MI355X, 1M-protein batches).
+#define SK_NR 8
+__device__ __constant__ const u32 sk_r_cand[SK_NR] = {2544, 2800, 3056, 3312, 3568, 3824, 3952, 4016};
+static const u32 sk_r_cand_host[SK_NR] = {2544, 2800, 3056, 3312, 3568, 3824, 3952, 4016};
 #define SK_PAD 160                  // >= KS_MAX_KSIZE + 24: slack behind the last residue for word reads
 #ifndef SK_MINW
 #define SK_MINW 6                   // waves per SIMD to compile for: 3 workgroups of 8 waves per CU
@@ -63,7 +70,8 @@ struct sk_args {
     u64 max_hash;
     u32 sfix;     // floor(2^48 / ((max_hash >> 32) + 1)): bucket multiplier = (n_windows * sfix) >> 16
     const u8 *lut; // 256-byte encode table for this moltype
-    u32 len_cap;   // sequences longer than this are not this launch's business
+    u32 R;         // tile stride in residues (see sk_r_cand)
+    u32 le_cap;    // a sequence whose LOCAL end lies beyond this is not this launch's business
     const u32 *seq_list; // MODE 0: tile_first[n_tiles + 1] (tile -> first sequence); MODE 1: one medium sequence per workgroup
     // MODE 0 writes the final CSR directly: hashes / abunds at csr positions, csr[s] per sequence
     u64 *out_hash;  // MODE 0: final hashes [n_windows]; MODE 1: lg_hash [n_res] (run of sequence s starts at offs[s])
@@ -122,6 +130,9 @@ KS_DEV u64 sk_hash_window(const u64 *w /* LDS words starting at pos8 */, u32 k, 
     return m.finish((u64)k);
 }
 
+// does the sequence at residue offset `start` with `len` residues end outside its shared tile's LDS window?
+KS_DEV bool sk_deferred(u64 start, u64 len, u32 R) { return start % R + len > SK_MED_MAX; }
+
 #define SK_SEQ_CAP 254 // sequence boundaries of a tile staged in LDS (tiles with more fall back to global reads)
 // per-element code: sequence (relative to the tile's first, 8 bits) | bucket (12 bits) | arrival slot (12 bits)
 #define SK_BO_B(x) (((x) >> 12) & 0xfffu)
@@ -156,7 +167,7 @@ KS_DEV void sk_load_seq(sk_seq &q, const sk_args &A, const sk_bounds &B, u32 s_e
     q.ls = B.at(q.s);
     q.le = B.at(q.s + 1);
     const u32 len = q.le - q.ls; // a clamped end only makes a too-long sequence look (still) too long
-    q.nw = (len >= A.k && len <= A.len_cap) ? (len - A.k + 1) : 0;
+    q.nw = (len >= A.k && q.le <= A.le_cap) ? (len - A.k + 1) : 0;
     q.mul = sk_bucket_mul(q.nw, A.sfix);
     q.ok = q.nw > 0;
 }
@@ -176,12 +187,12 @@ KS_DEV u32 sk_place_window(const sk_args &A, u32 p, u64 h, sk_seq &q, const sk_b
     return bo;
 }
 
-// tile_first[t] = first sequence whose start offset is >= t * SK_R (n_tiles + 1 entries): one parallel
+// tile_first[t] = first sequence whose start offset is >= t * R (n_tiles + 1 entries): one parallel
 // binary search per tile here instead of a serial, latency-bound one at the head of every workgroup
-__global__ __launch_bounds__(256) void k_tile_plan(const u64 *offs, u32 n_seqs, u32 n_tiles, u32 *tile_first) {
+__global__ __launch_bounds__(256) void k_tile_plan(const u64 *offs, u32 n_seqs, u32 n_tiles, u32 R, u32 *tile_first) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tiles) return;
-    tile_first[t] = t == n_tiles ? n_seqs : sk_lower_bound(offs, 0, n_seqs, (u64)t * SK_R);
+    tile_first[t] = t == n_tiles ? n_seqs : sk_lower_bound(offs, 0, n_seqs, (u64)t * R);
 }
 
 // MODE 0: shared tiles cut by residue range; MODE 1: one listed medium sequence per workgroup
@@ -210,11 +221,33 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     __shared__ u32 ext_seq[4], ext_cnt[4], ext_d[4];
     __shared__ unsigned long long base_s;
     u32 tile = blockIdx.x;
+    constexpr u32 NCH = (SK_TILE + SK_PAD) / 16; // 16-byte chunks of a staged tile
+    static_assert(NCH <= SK_THREADS, "one staging chunk per thread");
+    // A workgroup's start is a chain of dependent memory latencies (ticket -> tile plan -> offsets); everything that
+    // does not depend on the previous link is issued beside it: LDS zeroing and the LUT ride on the ticket atomic, and
+    // the tile's residues (MODE 0: a fixed window of SK_TILE bytes from tile * R) are requested with the plan entry.
+    u32 ticket_v = 0;
+    if (MODE == 0 && tid == 0) ticket_v = atomicAdd(&A.ticket[0], 1u);
+    if (tid < 256) lut_s[tid] = A.lut[tid];
+    for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
+    if (tid < SK_NFLAG) flagbits[tid] = 0;
+    if (tid == 0) { ext_n_heavy = 0; ext_n = 0; }
     if (MODE == 0) {
         // tiles are handed out in ticket order, so every predecessor a look-back waits for is already running
-        if (tid == 0) { tile_s = atomicAdd(&A.ticket[0], 1u); ext_n = 0; }
+        if (tid == 0) tile_s = ticket_v;
         __syncthreads();
         tile = tile_s;
+    }
+    uint4 rv = make_uint4(0, 0, 0, 0);
+    if (MODE == 0 && tid < NCH) {
+        const u64 g = (u64)tile * A.R + (u64)tid * 16; // R is a multiple of 16
+        if (g + 16 <= A.n_res) {
+            rv = *(const uint4 *)(A.res + g);
+        } else {
+            u32 t[4] = {0, 0, 0, 0};
+            for (u32 b = 0; b < 16 && g + b < A.n_res; b++) t[b >> 2] |= (u32)A.res[g + b] << (8 * (b & 3));
+            rv = make_uint4(t[0], t[1], t[2], t[3]);
+        }
     }
     u32 s_first, s_end;
     if (MODE == 1) { s_first = A.seq_list[tile]; s_end = s_first + 1; }
@@ -224,8 +257,8 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
             __hip_atomic_store(&A.tile_status[tile], SK_FLAG_AGG | 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    const u64 r0 = A.offs[s_first];
-    const u64 g0 = r0 & ~15ULL; // A.res is 16-byte aligned (checked on the host)
+    // local coordinates: MODE 0 counts from the tile's first byte, MODE 1 from the (aligned) start of its sequence
+    const u64 g0 = MODE == 0 ? (u64)tile * A.R : (A.offs[s_first] & ~15ULL); // A.res is 16-byte aligned (checked on the host)
     const u32 ns = s_end - s_first;
     sk_bounds B;
     B.loff = loff; B.goff = A.offs; B.g0 = g0; B.s_first = s_first; B.in_lds = ns <= SK_SEQ_CAP;
@@ -234,35 +267,34 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
             u64 v = A.offs[s_first + i] - g0;
             loff[i] = v > 0x7fffffffULL ? 0x7fffffffu : (u32)v;
         }
-    if (tid < 256) lut_s[tid] = A.lut[tid];
-    for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
-    if (tid < SK_NFLAG) flagbits[tid] = 0;
-    if (tid == 0) ext_n_heavy = 0;
-    u64 span_end = A.offs[s_end];
-    if (span_end > g0 + SK_TILE) span_end = g0 + SK_TILE;
-    __syncthreads();
 
     SK_STAMP_AT(0);
     // ---- phase 1: residues -> LDS through the encode LUT, 16 B per lane
-    for (u32 c = tid; c < (SK_TILE + SK_PAD) / 16; c += SK_THREADS) {
-        u64 g = g0 + (u64)c * 16;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (g < span_end) {
-            if (g + 16 <= A.n_res) {
-                v = *(const uint4 *)(A.res + g);
-            } else {
-                u32 t[4] = {0, 0, 0, 0};
-                for (u32 b = 0; b < 16 && g + b < A.n_res; b++) t[b >> 2] |= (u32)A.res[g + b] << (8 * (b & 3));
-                v = make_uint4(t[0], t[1], t[2], t[3]);
+    if (MODE == 1) {
+        u64 span_end = A.offs[s_end];
+        if (span_end > g0 + SK_TILE) span_end = g0 + SK_TILE;
+        if (tid < NCH) {
+            const u64 g = g0 + (u64)tid * 16;
+            if (g < span_end) {
+                if (g + 16 <= A.n_res) {
+                    rv = *(const uint4 *)(A.res + g);
+                } else {
+                    u32 t[4] = {0, 0, 0, 0};
+                    for (u32 b = 0; b < 16 && g + b < A.n_res; b++) t[b >> 2] |= (u32)A.res[g + b] << (8 * (b & 3));
+                    rv = make_uint4(t[0], t[1], t[2], t[3]);
+                }
             }
-            u32 in[4] = {v.x, v.y, v.z, v.w}, o[4];
-#pragma unroll
-            for (int d = 0; d < 4; d++)
-                o[d] = (u32)lut_s[in[d] & 255u] | ((u32)lut_s[(in[d] >> 8) & 255u] << 8) |
-                       ((u32)lut_s[(in[d] >> 16) & 255u] << 16) | ((u32)lut_s[in[d] >> 24] << 24);
-            v = make_uint4(o[0], o[1], o[2], o[3]);
         }
-        *(uint4 *)(res_b + (size_t)c * 16) = v;
+        __syncthreads(); // lut_s
+    }
+    if (tid < NCH) {
+        const u32 in[4] = {rv.x, rv.y, rv.z, rv.w};
+        u32 o[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            o[d] = (u32)lut_s[in[d] & 255u] | ((u32)lut_s[(in[d] >> 8) & 255u] << 8) |
+                   ((u32)lut_s[(in[d] >> 16) & 255u] << 16) | ((u32)lut_s[in[d] >> 24] << 24);
+        *(uint4 *)(res_b + (size_t)tid * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
 
@@ -283,16 +315,23 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     const u64 *wl = res_w + tid; // word at byte q0
     u64 h[SK_E];
     u32 bo[SK_E];
-    h[0] = sk_hash_window<0>(wl, A.k, A.seed);
-    h[1] = sk_hash_window<1>(wl, A.k, A.seed);
-    h[2] = sk_hash_window<2>(wl, A.k, A.seed);
-    h[3] = sk_hash_window<3>(wl, A.k, A.seed);
-    h[4] = sk_hash_window<4>(wl, A.k, A.seed);
-    h[5] = sk_hash_window<5>(wl, A.k, A.seed);
-    h[6] = sk_hash_window<6>(wl, A.k, A.seed);
-    h[7] = sk_hash_window<7>(wl, A.k, A.seed);
+    // a tile's sequences end, on average, two thirds of the way through its SK_TILE positions: the threads behind
+    // the last residue (whole waves, mostly) have nothing to hash
+    if (q0 < B.at(s_end)) {
+        h[0] = sk_hash_window<0>(wl, A.k, A.seed);
+        h[1] = sk_hash_window<1>(wl, A.k, A.seed);
+        h[2] = sk_hash_window<2>(wl, A.k, A.seed);
+        h[3] = sk_hash_window<3>(wl, A.k, A.seed);
+        h[4] = sk_hash_window<4>(wl, A.k, A.seed);
+        h[5] = sk_hash_window<5>(wl, A.k, A.seed);
+        h[6] = sk_hash_window<6>(wl, A.k, A.seed);
+        h[7] = sk_hash_window<7>(wl, A.k, A.seed);
 #pragma unroll
-    for (int i = 0; i < SK_E; i++) bo[i] = sk_place_window(A, q0 + i, h[i], q, B, s_end, cnt);
+        for (int i = 0; i < SK_E; i++) bo[i] = sk_place_window(A, q0 + i, h[i], q, B, s_end, cnt);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SK_E; i++) { h[i] = 0; bo[i] = 0xffffffffu; }
+    }
     __syncthreads();
 
     SK_STAMP_AT(2);
@@ -439,18 +478,19 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
         __syncthreads();
         SK_STAMP_AT(7);
         // into the side buffer at the sequence's own offset; k_place_long moves it once its CSR slot is known
+        const u64 r0 = A.offs[s_first];
         for (u32 d = tid; d < n_distinct; d += SK_THREADS) {
             A.out_hash[r0 + d] = tmp[d];
             A.out_abund[r0 + d] = abund_s[d];
         }
     } else {
-        // distinct rank at every sequence start; medium / long sequences that start inside this tile (at most
-        // 2-3) bring their unique counts from the earlier launches into the aggregate and the positions behind them
+        // distinct rank at every sequence start; a deferred (medium / long) sequence that starts inside this tile (at
+        // most one: the last) brings its unique count from the earlier launches into the aggregate
         for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
             const u32 ls = B.at(s), le = B.at(s + 1);
             const u32 d0 = drank(bstart(ls));
             if (B.in_lds) dseq[s - s_first] = (u16)d0;
-            if (le - ls > A.len_cap) {
+            if (le > A.le_cap) {
                 const u32 e = atomicAdd(&ext_n, 1u);
                 if (e < 4) { ext_seq[e] = s; ext_cnt[e] = A.counts[s]; ext_d[e] = d0; }
             }
@@ -598,12 +638,25 @@ struct sk_long_args {
 };
 
 // n_cls[0] = medium sequences (own tile), n_cls[1] = long sequences (global-slab path)
-__global__ __launch_bounds__(256) void k_find_long(const u64 *offs, u32 n_seqs, u32 *med_ids, u32 *long_ids, u32 *n_cls) {
-    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seqs) return;
-    u64 len = offs[s + 1] - offs[s];
-    if (len > SK_MED_MAX) long_ids[atomicAdd(&n_cls[1], 1u)] = s;
-    else if (len > SK_LS_MAX) med_ids[atomicAdd(&n_cls[0], 1u)] = s;
+__global__ __launch_bounds__(256) void k_find_long(const u64 *offs, u32 n_seqs, u32 R, u32 *med_ids, u32 *long_ids, u32 *n_cls) {
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 cls = 2; // 0 medium, 1 long, 2 neither
+    if (s < n_seqs) {
+        const u64 len = offs[s + 1] - offs[s];
+        if (len > SK_MED_MAX) cls = 1;
+        else if (sk_deferred(offs[s], len, R)) cls = 0;
+    }
+    // one atomic per wave and class (the lists are short but every thread would hit the same two counters)
+#pragma unroll
+    for (u32 c = 0; c < 2; c++) {
+        const u64 m = __ballot(cls == c);
+        if (m == 0) continue;
+        const u32 leader = (u32)__ffsll((long long)m) - 1u;
+        u32 base = 0;
+        if ((threadIdx.x & 63) == leader) base = atomicAdd(&n_cls[c], (u32)__popcll(m));
+        base = __shfl(base, (int)leader, 64);
+        if (cls == c) (c == 0 ? med_ids : long_ids)[base + ks_lane_lt_count(m)] = s;
+    }
 }
 
 // block-wide exclusive scan of a global u32 array in place; returns the total (uniform)
@@ -759,28 +812,41 @@ __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u64 *o
     }
 }
 
-// out[0] = k-mer windows, out[1] = longest sequence, out[2] = medium sequences, out[3] = long sequences
+// out[0] = k-mer windows, out[1] = longest sequence, out[2] = long sequences, out[4 + c] = medium (deferred but
+// tile-sized) sequences under tile stride sk_r_cand[c]
 __global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, u32 k, u64 *out) {
-    u64 w = 0, mx = 0, nm = 0, nl = 0;
+    u64 w = 0, mx = 0, nl = 0;
+    u32 nd[SK_NR];
+#pragma unroll
+    for (int c = 0; c < SK_NR; c++) nd[c] = 0;
     for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n_seqs; s += gridDim.x * blockDim.x) {
-        u64 len = offs[s + 1] - offs[s];
+        const u64 st = offs[s], len = offs[s + 1] - st;
         w += len >= k ? len - k + 1 : 0;
         mx = len > mx ? len : mx;
         nl += len > SK_MED_MAX;
-        nm += (len > SK_LS_MAX) & (len <= SK_MED_MAX);
+        if (len <= SK_MED_MAX) {
+            // (a sequence no longer than SK_MED_MAX + 1 - R fits wherever it starts: no 64-bit modulo for those; the
+            // two widest strides are only ever taken when EVERY sequence is that short, so they are not counted)
+#pragma unroll
+            for (int c = 0; c < SK_NR - 2; c++)
+                if (len + sk_r_cand[c] > SK_MED_MAX + 1) nd[c] += sk_deferred(st, len, sk_r_cand[c]) ? 1u : 0u;
+        }
     }
     for (int d = 32; d > 0; d >>= 1) {
         w += __shfl_down(w, d, 64);
-        nm += __shfl_down(nm, d, 64);
         nl += __shfl_down(nl, d, 64);
         u64 o = __shfl_down(mx, d, 64);
         mx = o > mx ? o : mx;
+#pragma unroll
+        for (int c = 0; c < SK_NR; c++) nd[c] += __shfl_down(nd[c], d, 64);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd((unsigned long long *)&out[0], (unsigned long long)w);
         atomicMax((unsigned long long *)&out[1], (unsigned long long)mx);
-        if (nm) atomicAdd((unsigned long long *)&out[2], (unsigned long long)nm);
-        if (nl) atomicAdd((unsigned long long *)&out[3], (unsigned long long)nl);
+        if (nl) atomicAdd((unsigned long long *)&out[2], (unsigned long long)nl);
+#pragma unroll
+        for (int c = 0; c < SK_NR; c++)
+            if (nd[c]) atomicAdd((unsigned long long *)&out[4 + c], (unsigned long long)nd[c]);
     }
 }
 
@@ -807,7 +873,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     u64 *slab64 = nullptr, *lg_hash = nullptr;
     u32 *slab32 = nullptr, *lg_abund = nullptr;
     u64 n_med = 0, n_long = 0;
-    u32 real_max = 0;
+    u32 real_max = 0, tile_R = sk_r_cand_host[0];
 #define SK_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
 #define SK_HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
 
@@ -822,20 +888,28 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     }
     {
         // windows, longest sequence, medium / long counts: one small D2H
-        SK_CHECK(ks_alloc(ctx, &d_stats, 4));
-        SK_HIPCHECK(hipMemsetAsync(d_stats, 0, 4 * sizeof(u64), ctx->stream));
+        SK_CHECK(ks_alloc(ctx, &d_stats, 4 + SK_NR));
+        SK_HIPCHECK(hipMemsetAsync(d_stats, 0, (4 + SK_NR) * sizeof(u64), ctx->stream));
         u32 g = (n_seqs + 1023) / 1024;
         if (g > 2048) g = 2048;
         ks_timer_begin(ctx, "seq_stats");
         hipLaunchKernelGGL(k_seq_stats, dim3(g), dim3(256), 0, ctx->stream, d_offs, n_seqs, p->ksize, d_stats);
         ks_timer_end(ctx);
-        SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, 4 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, (4 + SK_NR) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
         SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
         S->n_windows = ctx->h_pin[0];
         if (ctx->h_pin[1] > 0xfffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "sequence longer than 2^32 residues"); goto done; }
         real_max = (u32)ctx->h_pin[1];
-        n_med = ctx->h_pin[2];
-        n_long = ctx->h_pin[3];
+        n_long = ctx->h_pin[2];
+        {
+            // tile stride: fewest (tiles + 1.75 * deferred sequences), see sk_r_cand
+            double best = 0;
+            for (int c = 0; c < SK_NR; c++) {
+                if (c >= SK_NR - 2 && (u64)real_max + sk_r_cand_host[c] > SK_MED_MAX + 1) continue; // uncounted strides
+                const double cost = (double)(n_res / sk_r_cand_host[c] + 1) + 1.75 * (double)ctx->h_pin[4 + c];
+                if (c == 0 || cost < best) { best = cost; tile_R = sk_r_cand_host[c]; n_med = ctx->h_pin[4 + c]; }
+            }
+        }
     }
     {
         // final arrays sized by the window count (an upper bound on the kept hashes); the tile kernel writes
@@ -884,13 +958,13 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             SK_CHECK(ks_alloc(ctx, &n_cls, 2));
             SK_HIPCHECK(hipMemsetAsync(n_cls, 0, 2 * sizeof(u32), ctx->stream));
             ks_timer_begin(ctx, "find_long");
-            hipLaunchKernelGGL(k_find_long, dim3((n_seqs + 255) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, med_ids, long_ids, n_cls);
+            hipLaunchKernelGGL(k_find_long, dim3((n_seqs + 255) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, tile_R, med_ids, long_ids, n_cls);
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
         }
         if (n_med > 0) {
             sk_args M = A; // (keeps the posting arguments: a medium tile emits its own postings)
-            M.out_hash = lg_hash; M.out_abund = lg_abund; M.len_cap = SK_MED_MAX; M.seq_list = med_ids;
+            M.out_hash = lg_hash; M.out_abund = lg_abund; M.le_cap = SK_TILE; M.seq_list = med_ids; // local start <= 15, length <= SK_MED_MAX
             ks_timer_begin(ctx, "sketch_medium");
             hipLaunchKernelGGL(k_sketch_tiles<1>, dim3((u32)n_med), dim3(SK_THREADS), 0, ctx->stream, M);
             ks_timer_end(ctx);
@@ -919,15 +993,15 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         }
 
         // ---- shared tiles: hash + sort/unique + CSR placement in one kernel (decoupled look-back across tiles)
-        const u64 n_tiles = n_res / SK_R + 1;
+        const u64 n_tiles = n_res / tile_R + 1;
         if (n_tiles > 0x7ffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "batch too large"); goto done; }
         SK_CHECK(ks_alloc(ctx, &tile_first, (size_t)n_tiles + 1));
         SK_CHECK(ks_alloc(ctx, &tile_status, (size_t)n_tiles));
         SK_HIPCHECK(hipMemsetAsync(tile_status, 0, (size_t)n_tiles * sizeof(unsigned long long), ctx->stream));
         ks_timer_begin(ctx, "tile_plan");
-        hipLaunchKernelGGL(k_tile_plan, dim3((u32)((n_tiles + 256) / 256)), dim3(256), 0, ctx->stream, d_offs, n_seqs, (u32)n_tiles, tile_first);
+        hipLaunchKernelGGL(k_tile_plan, dim3((u32)((n_tiles + 256) / 256)), dim3(256), 0, ctx->stream, d_offs, n_seqs, (u32)n_tiles, tile_R, tile_first);
         ks_timer_end(ctx);
-        A.seq_list = tile_first; A.len_cap = SK_LS_MAX;
+        A.seq_list = tile_first; A.le_cap = SK_MED_MAX; A.R = tile_R;
         A.out_hash = S->d_hashes; A.out_abund = S->d_abunds; A.csr = S->d_offsets;
         A.tile_status = tile_status; A.n_tiles = (u32)n_tiles;
         ks_timer_begin(ctx, "sketch_tiles");

@@ -120,6 +120,20 @@ def test_sketch_ragged_and_edge_inputs(ctx):
         assert_sketch_parity(ctx, res, offs, k, scaled, mol)
 
 
+@pytest.mark.parametrize("lo,hi,n", [(1, 60, 30000), (20, 128, 20000), (200, 300, 8000), (600, 900, 4000),
+                                     (1000, 1600, 2500), (1500, 4080, 1200), (1, 4200, 1500)])
+def test_sketch_every_tile_stride(ctx, lo, hi, n):
+    """The tile stride is chosen per batch from the length distribution (peptides: widest stride, nothing deferred;
+    long proteins: narrow stride, many sequences deferred to tiles of their own): parity in every regime."""
+    rng = np.random.default_rng(hi)
+    lens = rng.integers(lo, hi + 1, n).astype(np.uint64)
+    offs = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    res = rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8), size=int(offs[-1])).astype(np.uint8)
+    assert_sketch_parity(ctx, res, offs, 10, 1, "protein")
+    assert_sketch_parity(ctx, res, offs, 7, 3, "hp")
+
+
 def test_sketch_empty_batches(ctx):
     S = ctx.sketch_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64), 5, 1, "protein")
     assert S.n_seqs == 0 and S.n_hashes == 0

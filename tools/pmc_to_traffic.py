@@ -15,11 +15,11 @@ import sys
 
 NAMES = {  # profiler kernel name prefix -> library timing name
     "void k_sketch_tiles<0>": "sketch_tiles",
-    "void k_radix_scatter<unsigned int, 1, true>": "radix_scatter.qpart",
-    "void k_radix_scatter<unsigned int, 1, false>": "radix_scatter.qpart.dense",
+    "k_bucket_scatter": "bucket_scatter",
+    "void k_radix_scatter<unsigned int, 1>": "radix_scatter.qpart",
     "void k_radix_hist<1>": "radix_hist.qpart",
     "k_join_buckets": "join_buckets",
-    "void k_radix_scatter<unsigned long, 0, false>": "radix_scatter.index",
+    "void k_radix_scatter<unsigned long, 0>": "radix_scatter.index",
 }
 
 
