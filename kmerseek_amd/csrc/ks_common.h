@@ -126,6 +126,7 @@ struct ks_index {
     u64 *d_keys;   // sorted hashes
     u32 *d_tids;   // target id per posting
     u32 *d_abunds; // target abundance per posting
+    u32 max_abund; // largest of them: how many low bits of a packed match record the abundance needs
 };
 
 struct ks_hits {
@@ -166,6 +167,9 @@ int ks_radix_sort_u32(ks_ctx *ctx, int tag, const u64 *keys_in, const u32 *vals_
                       const ks_rs_segments *seg = nullptr, u32 pfxK = 0);
 // last partition pass of a search without a histogram: segmented input -> 2^pbits buckets of capacity bcap;
 // bcur[bucket] ends as the bucket's record count, status[1] != 0 if some bucket overflowed
+// keys only (the match list with the abundance packed under the ids)
+int ks_radix_sort_keys(ks_ctx *ctx, int tag, const u64 *keys_in, u64 *ka, u64 *kb, u64 n, const int *shifts, int n_shifts,
+                       u64 **keys_out);
 int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, const ks_rs_segments *seg, int shift,
                           u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status);
 int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_in, u64 *ka, u64 *va, u64 *kb, u64 *vb,

@@ -2,6 +2,7 @@
 // radix sort (8-bit digits) for (u64 key, u32|u64 value) records.  Integer / HBM-bound work:
 // coalesced 8..16-B per-lane accesses, LDS-staged scatter so each digit leaves as a contiguous run.
 #include "ks_device.h"
+#include <type_traits>
 
 // =============================================================================================
 // scans
@@ -196,6 +197,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 
     if (threadIdx.x < 256) hist[(u64)threadIdx.x * nblocks + blockIdx.x] = bins[threadIdx.x];
 }
 
+struct ks_noval {}; // value type of a keys-only sort: every value move below compiles away
+
 // Stable scatter.  Item order inside a tile is (wave, round, lane) = ascending global index, so
 // ranks computed per wave with ballot-matching + per-wave digit counters preserve input order.
 // Records are staged through ONE LDS buffer in local digit order (keys first, then values), so each
@@ -210,6 +213,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
     __shared__ u32 scan_smem[RS_WAVES + 1];
     __shared__ __attribute__((aligned(16))) u64 stage[RS_TILE];
 
+    constexpr bool HAS_V = !std::is_same<V, ks_noval>::value;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 256) {
         for (int w = 0; w < RS_WAVES; w++) wcnt[w][tid] = 0;
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
         const u32 li = wloc + (u32)r * 64 + lane;
         const bool valid = li < nvalid;
         key[r] = valid ? kin[tile_base + li] : ~0ULL;
-        val[r] = valid ? vin[tile_base + li] : (V)0;
+        if constexpr (HAS_V) val[r] = valid ? vin[tile_base + li] : (V)0;
     }
 #pragma unroll
     for (int r = 0; r < RS_IPT; r++) {
@@ -287,15 +291,17 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
             kout[gdst[i]] = k;
         }
     }
-    __syncthreads();
-    V *vstage = (V *)stage;
+    if constexpr (HAS_V) {
+        __syncthreads();
+        V *vstage = (V *)stage;
 #pragma unroll
-    for (int r = 0; r < RS_IPT; r++) vstage[pos[r]] = val[r];
-    __syncthreads();
+        for (int r = 0; r < RS_IPT; r++) vstage[pos[r]] = val[r];
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RS_IPT; i++) {
-        u32 p = (u32)i * RS_THREADS + tid;
-        if (gdst[i] != ~0ULL) vout[gdst[i]] = vstage[p];
+        for (int i = 0; i < RS_IPT; i++) {
+            u32 p = (u32)i * RS_THREADS + tid;
+            if (gdst[i] != ~0ULL) vout[gdst[i]] = vstage[p];
+        }
     }
 }
 
@@ -446,6 +452,13 @@ int ks_radix_sort_u32(ks_ctx *ctx, int tag, const u64 *keys_in, const u32 *vals_
     if (tag == KS_SORT_QPART)
         return radix_sort_tagged<u32, KS_SORT_QPART>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out, seg, pfxK);
     return radix_sort_tagged<u32, KS_SORT_PAIRS>(ctx, keys_in, vals_in, ka, va, kb, vb, n, shifts, n_shifts, keys_out, vals_out, seg, pfxK);
+}
+int ks_radix_sort_keys(ks_ctx *ctx, int tag, const u64 *keys_in, u64 *ka, u64 *kb, u64 n, const int *shifts, int n_shifts,
+                       u64 **keys_out) {
+    (void)tag;
+    ks_noval *vo = nullptr;
+    return radix_sort_tagged<ks_noval, KS_SORT_PAIRS>(ctx, keys_in, (const ks_noval *)nullptr, ka, (ks_noval *)nullptr, kb,
+                                                      (ks_noval *)nullptr, n, shifts, n_shifts, keys_out, &vo, nullptr, 0u);
 }
 int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_in, u64 *ka, u64 *va, u64 *kb, u64 *vb, u64 n,
                       const int *shifts, int n_shifts, u64 **keys_out, u64 **vals_out) {

@@ -30,12 +30,20 @@ __global__ __launch_bounds__(256) void k_fill_query_vals(const u64 *csr, u32 n_s
     for (u64 j = b + (threadIdx.x & 63); j < e; j += 64) vals[j] = s;
 }
 
-__global__ __launch_bounds__(256) void k_split_vals(const u64 *vals, u64 n, u32 *tids, u32 *abunds) {
+__global__ __launch_bounds__(256) void k_split_vals(const u64 *vals, u64 n, u32 *tids, u32 *abunds, u32 *max_abund) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u64 v = vals[i];
-    tids[i] = (u32)v;
-    abunds[i] = (u32)(v >> 32);
+    u32 a = 0;
+    if (i < n) {
+        u64 v = vals[i];
+        tids[i] = (u32)v;
+        a = (u32)(v >> 32);
+        abunds[i] = a;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        const u32 o = __shfl_down(a, d, 64);
+        a = o > a ? o : a;
+    }
+    if ((threadIdx.x & 63) == 0 && a) atomicMax(max_abund, a);
 }
 
 int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
@@ -49,6 +57,7 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
     ix->n_postings = t->n_hashes;
     const u64 n = t->n_hashes;
     u64 *k0 = nullptr, *k1 = nullptr, *v0 = nullptr, *v1 = nullptr;
+    u32 *d_max = nullptr;
     int st = KS_OK;
 #define IX_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
 #define IX_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
@@ -69,10 +78,15 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
         u64 *ks = nullptr, *vs = nullptr;
         // v0 holds the input values, so the first pass must land in (k1, v1): pass it as the "a" pair
         IX_CHECK(ks_radix_sort_u64(ctx, KS_SORT_INDEX, t->d_hashes, v0, k1, v1, k0, v0, n, shifts, 8, &ks, &vs));
+        IX_CHECK(ks_alloc(ctx, &d_max, 1));
+        IX_HIP(hipMemsetAsync(d_max, 0, sizeof(u32), ctx->stream));
         ks_timer_begin(ctx, "split_vals");
-        hipLaunchKernelGGL(k_split_vals, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u64 *)vs, n, ix->d_tids, ix->d_abunds);
+        hipLaunchKernelGGL(k_split_vals, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u64 *)vs, n, ix->d_tids, ix->d_abunds, d_max);
         ks_timer_end(ctx);
         IX_HIP(hipGetLastError());
+        IX_HIP(hipMemcpyAsync(ctx->h_pin, d_max, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        IX_HIP(hipStreamSynchronize(ctx->stream));
+        ix->max_abund = *(u32 *)ctx->h_pin;
         // keep the sorted key buffer, release the other
         if (ks == k0) { ix->d_keys = k0; k0 = nullptr; } else { ix->d_keys = k1; k1 = nullptr; }
     } else {
@@ -80,7 +94,7 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
     }
     IX_HIP(hipStreamSynchronize(ctx->stream));
 done:
-    ks_pool_free(ctx, k0); ks_pool_free(ctx, k1); ks_pool_free(ctx, v0); ks_pool_free(ctx, v1);
+    ks_pool_free(ctx, k0); ks_pool_free(ctx, k1); ks_pool_free(ctx, v0); ks_pool_free(ctx, v1); ks_pool_free(ctx, d_max);
     if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_index_free(ix); return st; }
     *out = ix;
     return KS_OK;
@@ -109,6 +123,12 @@ done:
 #define JN_CAP 6144
 #endif
 //                          index keys staged per chunk: 48 KiB of LDS -> 3 workgroups (24 waves) per CU
+
+static int bits_for_value(u32 v) { // bits needed to represent the value v itself (>= 1)
+    int b = 1;
+    while (b < 32 && (v >> b)) b++;
+    return b;
+}
 
 static int bits_for(u32 n) { // bits needed to represent ids 0..n-1
     int b = 0;
@@ -172,7 +192,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
                                                              const u32 *itids, const u32 *iabunds, const u64 *q_lo,
                                                              const u64 *q_hi, const u64 *dir_t, u64 *pair_keys,
                                                              u32 *pair_vals, u64 cap, unsigned long long *cursor,
-                                                             int tbits) {
+                                                             int tbits, int abits) {
     __shared__ u64 lk[JN_CAP];
     __shared__ u32 scan_smem[JN_THREADS / 64 + 1];
     __shared__ unsigned long long base_s;
@@ -218,8 +238,9 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
                         const u64 j0 = c0 + (info[e] & 0xffffu);
                         for (u32 j = 0; j < c; j++, slot++) {
                             if (slot < cap) {
-                                pair_keys[slot] = ((u64)q << tbits) | itids[j0 + j]; // ids packed tight: fewer sort passes
-                                pair_vals[slot] = iabunds[j0 + j];
+                                const u64 ids = ((u64)q << tbits) | itids[j0 + j]; // ids packed tight: fewer sort passes
+                                if (pair_vals) { pair_keys[slot] = ids; pair_vals[slot] = iabunds[j0 + j]; }
+                                else pair_keys[slot] = (ids << abits) | iabunds[j0 + j]; // one 8-byte record per match
                             }
                         }
                     }
@@ -234,30 +255,33 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
 // ---------------------------------------------------------------------------------------------
 // pair reduce: sorted (qid<<32|tid, abund) -> COO rows
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pair_heads(const u64 *keys, u64 n, u32 *heads) {
+// `abits` low bits of a key are payload (the packed abundance, 0 when the values travel separately): rows are runs of
+// equal keys >> abits
+__global__ __launch_bounds__(256) void k_pair_heads(const u64 *keys, u64 n, u32 *heads, int abits) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    heads[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    heads[i] = (i == 0 || (keys[i] >> abits) != (keys[i - 1] >> abits)) ? 1u : 0u;
 }
 
 // hidx = exclusive scan of heads; row r starts where hidx steps from r to r+1
-__global__ __launch_bounds__(256) void k_pair_rows(const u64 *keys, const u32 *vals, const u32 *hidx, u64 n, u32 n_rows,
-                                                   u64 *row_start) {
+__global__ __launch_bounds__(256) void k_pair_rows(const u64 *keys, const u32 *hidx, u64 n, u32 n_rows, u64 *row_start, int abits) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    bool head = (i == 0) || keys[i] != keys[i - 1];
+    bool head = (i == 0) || (keys[i] >> abits) != (keys[i - 1] >> abits);
     if (head) row_start[hidx[i]] = i;
     if (i == 0) row_start[n_rows] = n;
 }
 
 __global__ __launch_bounds__(256) void k_pair_emit(const u64 *keys, const u32 *vals, const u64 *row_start, u32 n_rows,
-                                                   u32 *qid, u32 *tid, u32 *isect, u64 *nw, int tbits) {
+                                                   u32 *qid, u32 *tid, u32 *isect, u64 *nw, int tbits, int abits) {
     u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     u64 b = row_start[r], e = row_start[r + 1];
-    u64 k = keys[b];
+    const u64 k = keys[b] >> abits;
+    const u64 amask = (1ULL << abits) - 1ULL;
     u64 w = 0;
-    for (u64 j = b; j < e; j++) w += vals[j];
+    if (vals) for (u64 j = b; j < e; j++) w += vals[j];
+    else for (u64 j = b; j < e; j++) w += keys[j] & amask;
     qid[r] = (u32)(k >> tbits);
     tid[r] = (u32)(k & ((1ULL << tbits) - 1ULL));
     isect[r] = (u32)(e - b);
@@ -291,6 +315,12 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         const int pbits = ks_join_pbits(n_t);
         const u32 n_buckets = 1u << pbits;
         const int tbits = bits_for(ix->n_targets); // pair key = qid << tbits | tid
+        // a match is one 8-byte record (qid, tid, target abundance) whenever the three fit 64 bits — always, short of
+        // ~10^5 x 10^5 proteins with 2^30-fold repeats — so the match sort moves keys only; else ids and abundance travel apart
+        const int qbits = bits_for(q->n_seqs);
+        int abits = bits_for_value(ix->max_abund);
+        const bool packed = tbits + qbits + abits <= 64 && !getenv("KS_DEBUG_UNPACKED_PAIRS");
+        if (!packed) abits = 0;
         const u32 pfxK = ks_join_prefix_mul(pbits, ks_max_hash(ix->params.scaled));
         SE_CHECK(ks_alloc(ctx, &dir_q, (size_t)2 * n_buckets + 2));
         SE_CHECK(ks_alloc(ctx, &dir_t, (size_t)n_buckets + 1));
@@ -362,12 +392,13 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
             // join, with a retry if the match list outgrows its first guess
             bool overflowed = false;
             for (int attempt = 0; attempt < 2; attempt++) {
-                SE_CHECK(ks_alloc(ctx, &pk0, (size_t)cap)); SE_CHECK(ks_alloc(ctx, &pv0, (size_t)cap));
+                SE_CHECK(ks_alloc(ctx, &pk0, (size_t)cap));
+                if (!packed) SE_CHECK(ks_alloc(ctx, &pv0, (size_t)cap));
                 SE_HIP(hipMemsetAsync(cursor, 0, sizeof(u64), ctx->stream));
                 ks_timer_begin(ctx, "join_buckets");
                 hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
                                    (const u32 *)qv, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds,
-                                   q_lo, q_hi, (const u64 *)dir_t, pk0, pv0, cap, cursor, tbits);
+                                   q_lo, q_hi, (const u64 *)dir_t, pk0, pv0, cap, cursor, tbits, abits);
                 ks_timer_end(ctx);
                 SE_HIP(hipGetLastError());
                 SE_HIP(hipMemcpyAsync(ctx->h_pin, cursor, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
@@ -399,21 +430,23 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
             goto done;
         }
         // sort matches by (qid, tid) on the live id bits only
-        SE_CHECK(ks_alloc(ctx, &pk1, (size_t)n_pairs)); SE_CHECK(ks_alloc(ctx, &pv1, (size_t)n_pairs));
+        SE_CHECK(ks_alloc(ctx, &pk1, (size_t)n_pairs));
+        if (!packed) SE_CHECK(ks_alloc(ctx, &pv1, (size_t)n_pairs));
         u64 *pk = nullptr;
         u32 *pv = nullptr;
         {
             int shifts[8], ns = 0;
-            for (int sh = 0; sh < tbits + bits_for(q->n_seqs); sh += 8) shifts[ns++] = sh;
+            for (int sh = 0; sh < tbits + qbits; sh += 8) shifts[ns++] = abits + sh;
             // the match list (pk0, pv0) is scratch from here on: ping-pong with (pk1, pv1)
-            SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_PAIRS, pk0, pv0, pk0, pv0, pk1, pv1, n_pairs, shifts, ns, &pk, &pv));
+            if (packed) SE_CHECK(ks_radix_sort_keys(ctx, KS_SORT_PAIRS, pk0, pk0, pk1, n_pairs, shifts, ns, &pk));
+            else SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_PAIRS, pk0, pv0, pk0, pv0, pk1, pv1, n_pairs, shifts, ns, &pk, &pv));
         }
         // run-length reduce
         SE_CHECK(ks_alloc(ctx, &heads, (size_t)n_pairs));
         SE_CHECK(ks_alloc(ctx, &d_nrows, 1));
         const u32 gp = (u32)((n_pairs + 255) / 256);
         ks_timer_begin(ctx, "pair_heads");
-        hipLaunchKernelGGL(k_pair_heads, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, n_pairs, heads);
+        hipLaunchKernelGGL(k_pair_heads, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, n_pairs, heads, abits);
         ks_timer_end(ctx);
         SE_CHECK(ks_scan_u32_inplace(ctx, heads, n_pairs, d_nrows));
         SE_HIP(hipMemcpyAsync(ctx->h_pin, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
@@ -424,12 +457,12 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         SE_CHECK(ks_alloc(ctx, &H->d_qid, (size_t)n_rows)); SE_CHECK(ks_alloc(ctx, &H->d_tid, (size_t)n_rows));
         SE_CHECK(ks_alloc(ctx, &H->d_isect, (size_t)n_rows)); SE_CHECK(ks_alloc(ctx, &H->d_nw, (size_t)n_rows));
         ks_timer_begin(ctx, "pair_rows");
-        hipLaunchKernelGGL(k_pair_rows, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv, (const u32 *)heads,
-                           n_pairs, n_rows, row_start);
+        hipLaunchKernelGGL(k_pair_rows, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)heads, n_pairs, n_rows,
+                           row_start, abits);
         ks_timer_end(ctx);
         ks_timer_begin(ctx, "pair_emit");
         hipLaunchKernelGGL(k_pair_emit, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv,
-                           (const u64 *)row_start, n_rows, H->d_qid, H->d_tid, H->d_isect, H->d_nw, tbits);
+                           (const u64 *)row_start, n_rows, H->d_qid, H->d_tid, H->d_isect, H->d_nw, tbits, abits);
         ks_timer_end(ctx);
         SE_HIP(hipGetLastError());
         SE_HIP(hipStreamSynchronize(ctx->stream));
@@ -491,7 +524,7 @@ int ks_union_impl(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out) {
         UN_CHECK(ks_alloc(ctx, &d_nrows, 1));
         const u32 g = (u32)((n + 255) / 256);
         ks_timer_begin(ctx, "pair_heads");
-        hipLaunchKernelGGL(k_pair_heads, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)ks, n, heads);
+        hipLaunchKernelGGL(k_pair_heads, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)ks, n, heads, 0);
         ks_timer_end(ctx);
         UN_CHECK(ks_scan_u32_inplace(ctx, heads, n, d_nrows));
         UN_HIP(hipMemcpyAsync(ctx->h_pin, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
@@ -501,7 +534,7 @@ int ks_union_impl(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out) {
         UN_CHECK(ks_alloc(ctx, &row_start, (size_t)n_rows + 1));
         UN_CHECK(ks_alloc(ctx, &U->d_hashes, (size_t)n_rows)); UN_CHECK(ks_alloc(ctx, &U->d_abunds, (size_t)n_rows));
         ks_timer_begin(ctx, "pair_rows");
-        hipLaunchKernelGGL(k_pair_rows, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)ks, (const u32 *)vs, (const u32 *)heads, n, n_rows, row_start);
+        hipLaunchKernelGGL(k_pair_rows, dim3(g), dim3(256), 0, ctx->stream, (const u64 *)ks, (const u32 *)heads, n, n_rows, row_start, 0);
         ks_timer_end(ctx);
         ks_timer_begin(ctx, "union_emit");
         hipLaunchKernelGGL(k_union_emit, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream, (const u64 *)ks, (const u32 *)vs,

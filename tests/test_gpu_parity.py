@@ -354,3 +354,20 @@ def test_bucket_scatter_overflow_falls_back_to_dense_partition(ctx):
     assert (want[1] == 11).sum() >= 1500
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+
+
+def test_unpacked_match_records_equal_packed(ctx, monkeypatch):
+    """Matches normally travel as one 8-byte record (ids + target abundance packed); the 12-byte key + value form is
+    kept for id / abundance ranges that do not fit 64 bits.  Both must give the same rows."""
+    t_res, t_offs = synth.proteome(3000, stream=23)
+    q_res, q_offs = synth.queries(1500, t_res, t_offs, stream=24)
+    T = ctx.sketch_batch(t_res, t_offs, 7, 1, "hp")  # hp k=7: heavy repeats, abundances well above 1
+    Q = ctx.sketch_batch(q_res, q_offs, 7, 1, "hp")
+    ix = ctx.index_build(T)
+    a = ctx.search(ix, Q).to_host()
+    monkeypatch.setenv("KS_DEBUG_UNPACKED_PAIRS", "1")
+    b = ctx.search(ix, Q).to_host()
+    monkeypatch.delenv("KS_DEBUG_UNPACKED_PAIRS")
+    assert len(a[0]) > 0
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
