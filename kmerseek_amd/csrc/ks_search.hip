@@ -272,20 +272,41 @@ __global__ __launch_bounds__(256) void k_pair_rows(const u64 *keys, const u32 *h
     if (i == 0) row_start[n_rows] = n;
 }
 
-__global__ __launch_bounds__(256) void k_pair_emit(const u64 *keys, const u32 *vals, const u64 *row_start, u32 n_rows,
-                                                   u32 *qid, u32 *tid, u32 *isect, u64 *nw, int tbits, int abits) {
-    u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
-    u64 b = row_start[r], e = row_start[r + 1];
-    const u64 k = keys[b] >> abits;
-    const u64 amask = (1ULL << abits) - 1ULL;
-    u64 w = 0;
-    if (vals) for (u64 j = b; j < e; j++) w += vals[j];
-    else for (u64 j = b; j < e; j++) w += keys[j] & amask;
-    qid[r] = (u32)(k >> tbits);
-    tid[r] = (u32)(k & ((1ULL << tbits) - 1ULL));
-    isect[r] = (u32)(e - b);
-    nw[r] = w;
+// One pass over the sorted match list, coalesced: element i belongs to row hidx[i] (+1 if it is not a head, -1 based);
+// a wave sums abundance and count per row with a segmented shuffle scan and the last lane of each row segment adds the
+// partial to the row (rows span waves, so the adds are atomic: ~2 per wave).  Heads write the ids.
+__global__ __launch_bounds__(256) void k_pair_reduce(const u64 *keys, const u32 *vals, const u32 *hidx, u64 n, u32 *qid,
+                                                     u32 *tid, u32 *isect, unsigned long long *nw, int tbits, int abits) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 lane = threadIdx.x & 63;
+    const bool live = i < n;
+    u64 k = 0, w = 0;
+    u32 row = 0xffffffffu, c = 0;
+    bool head = false;
+    if (live) {
+        k = keys[i];
+        head = i == 0 || (keys[i - 1] >> abits) != (k >> abits);
+        row = hidx[i] - (head ? 0u : 1u);
+        w = vals ? (u64)vals[i] : (k & ((1ULL << abits) - 1ULL));
+        c = 1;
+        if (head) {
+            const u64 ids = k >> abits;
+            qid[row] = (u32)(ids >> tbits);
+            tid[row] = (u32)(ids & ((1ULL << tbits) - 1ULL));
+        }
+    }
+    // inclusive segmented scan (segments = equal row, rows ascend)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 ow = __shfl_up(w, d, 64);
+        const u32 oc = __shfl_up(c, d, 64), orow = __shfl_up(row, d, 64);
+        if (lane >= (u32)d && orow == row) { w += ow; c += oc; }
+    }
+    const u32 nrow = __shfl_down(row, 1, 64);
+    if (live && (lane == 63 || nrow != row)) {
+        atomicAdd(&isect[row], c);
+        atomicAdd(&nw[row], (unsigned long long)w);
+    }
 }
 
 int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out) {
@@ -453,16 +474,13 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         SE_HIP(hipStreamSynchronize(ctx->stream));
         const u32 n_rows = *(u32 *)ctx->h_pin;
         H->n_hits = n_rows;
-        SE_CHECK(ks_alloc(ctx, &row_start, (size_t)n_rows + 1));
         SE_CHECK(ks_alloc(ctx, &H->d_qid, (size_t)n_rows)); SE_CHECK(ks_alloc(ctx, &H->d_tid, (size_t)n_rows));
         SE_CHECK(ks_alloc(ctx, &H->d_isect, (size_t)n_rows)); SE_CHECK(ks_alloc(ctx, &H->d_nw, (size_t)n_rows));
-        ks_timer_begin(ctx, "pair_rows");
-        hipLaunchKernelGGL(k_pair_rows, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)heads, n_pairs, n_rows,
-                           row_start, abits);
-        ks_timer_end(ctx);
-        ks_timer_begin(ctx, "pair_emit");
-        hipLaunchKernelGGL(k_pair_emit, dim3((n_rows + 255) / 256), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv,
-                           (const u64 *)row_start, n_rows, H->d_qid, H->d_tid, H->d_isect, H->d_nw, tbits, abits);
+        SE_HIP(hipMemsetAsync(H->d_isect, 0, (size_t)n_rows * sizeof(u32), ctx->stream));
+        SE_HIP(hipMemsetAsync(H->d_nw, 0, (size_t)n_rows * sizeof(u64), ctx->stream));
+        ks_timer_begin(ctx, "pair_reduce");
+        hipLaunchKernelGGL(k_pair_reduce, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv, (const u32 *)heads,
+                           n_pairs, H->d_qid, H->d_tid, H->d_isect, (unsigned long long *)H->d_nw, tbits, abits);
         ks_timer_end(ctx);
         SE_HIP(hipGetLastError());
         SE_HIP(hipStreamSynchronize(ctx->stream));
