@@ -184,14 +184,15 @@ def main():
     # ---- roofline of the dominant kernel (HIP-event durations on the launch stream, this process)
     n_q_res = len(q_res_h)
     algo_bytes = {
-        # sketch: L residues read + 12 B per unique kept hash written + 8 B offset per sequence
-        "sketch_tiles": n_q_res + 12 * n_q_hashes + 8 * args.queries,
-        "sketch_gather": 24 * n_q_hashes,
+        # sketch: L residues read + 12 B per unique kept hash written + 8 B offset per sequence, plus —
+        # the query launches also ARE the first partition pass of the search — one 12-B posting written per kept hash
+        "sketch_tiles": n_q_res + 12 * n_q_hashes + 8 * args.queries + 12 * n_q_hashes,
         # one partition pass moves each (hash u64, qid u32) posting once in, once out
         "bucket_scatter": 24 * n_q_hashes,
         "radix_hist.qpart": 8 * n_q_hashes,
-        # join: 12 B per query posting + 12 B per index posting read once + 16 B per emitted pair
-        "join_buckets": 12 * n_q_hashes + 12 * n_t_postings + 16 * n_pairs,
+        # join: 12 B per query posting + 12 B per index posting read once + one packed 8-B record
+        # (qid, tid, abundance) per emitted pair
+        "join_buckets": 12 * n_q_hashes + 12 * n_t_postings + 8 * n_pairs,
     }
     per_kernel = {name: {"launches_per_step": n, "ms_per_step": ms} for name, (n, ms) in timing_all.items()}
     def roof(name):

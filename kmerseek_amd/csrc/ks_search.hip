@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void k_split_vals(const u64 *vals, u64 n, u32 
         const u32 o = __shfl_down(a, d, 64);
         a = o > a ? o : a;
     }
-    if ((threadIdx.x & 63) == 0 && a) atomicMax(max_abund, a);
+    if ((threadIdx.x & 63) == 0 && a > *max_abund) atomicMax(max_abund, a); // (plain read first: almost every wave's maximum is already covered)
 }
 
 int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
