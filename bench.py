@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--scaled", type=int, default=1)
     ap.add_argument("--moltype", default="protein")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the side measurements (sketch-only, end-to-end, device ceilings)")
     ap.add_argument("--cpu-sample-queries", type=int, default=0, help="0 = auto (aim at ~15 s of CPU work)")
     return ap.parse_args()
 
@@ -164,6 +165,41 @@ def main():
     ctx.timing_enable(False)
     timing_all = {k_: (n_ / 2, ms_ / 2) for k_, (n_, ms_) in ctx.timing().items()}
 
+    # ---- SURVEY §8(d) side lines (rank 0, after the timed region; none of them is `value`)
+    aux = None
+    if rank == 0 and not args.no_aux:
+        aux = {}
+        # device-resident sketch alone (both halves of "hashed + matched" separately)
+        torch.cuda.synchronize(dev)
+        c0 = time.perf_counter()
+        for _ in range(3):
+            Q = ctx.sketch_batch_device(q_res.data_ptr(), q_off.data_ptr(), args.queries, len(q_res_h), k, scaled, mol)
+            Q.free()
+        torch.cuda.synchronize(dev)
+        aux["kmers_sketched_per_s_device_resident"] = 3 * q_windows / (time.perf_counter() - c0)
+        # end to end from host buffers: H2D of residues + offsets, sketch, search, D2H of the hit rows (and of the CSR)
+        c0 = time.perf_counter()
+        Q = ctx.sketch_batch(q_res_h, q_off_h, k, scaled, mol)
+        H = ctx.search(index, Q)
+        rows = H.to_host()
+        c1 = time.perf_counter()
+        csr = Q.to_host()
+        c2 = time.perf_counter()
+        aux["end_to_end_host_buffers"] = {
+            "kmers_per_s_hits_to_host": q_windows / (c1 - c0), "kmers_per_s_hits_and_sketches_to_host": q_windows / (c2 - c0),
+            "h2d_bytes": int(q_res_h.nbytes + q_off_h.nbytes), "d2h_hit_bytes": int(sum(a.nbytes for a in rows)),
+            "d2h_sketch_bytes": int(sum(a.nbytes for a in csr)),
+            "note": "single call, pageable host arrays, no overlap of copy and compute; never the headline value"}
+        del rows, csr
+        H.free()
+        Q.free()
+        try:
+            r = ctx.device_rates()
+            aux["device"] = {"name": torch.cuda.get_device_name(dev), "hbm_nominal_gb_per_s_from_properties": r["nominal_gb_per_s"],
+                             "d2d_copy_gb_per_s_measured": r["copy_gb_per_s"], "u64_gmul_per_s_measured": r["u64_gmul_per_s"]}
+        except Exception as e:  # a side line must not cost the headline
+            aux["device"] = {"error": str(e)}
+
     tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     tot = torch.tensor([q_windows, args.queries, stats[1]], dtype=torch.int64, device=cdev)
     if world > 1:
@@ -269,7 +305,16 @@ def main():
         "hits": all_hits, "matched_posting_pairs": n_pairs,
         "index_build_s": index_build_s, "datagen_s": gen_s,
         "roofline": roofline, "cpu_baseline": cpu, "roofline_other_kernels": roofline_others, "kernels": per_kernel,
+        "aux": aux,
     }
+    if aux and isinstance(aux.get("device"), dict) and aux["device"].get("u64_gmul_per_s_measured") and "sketch_tiles" in timing:
+        # integer-ALU line of the sketch kernel: 64-bit multiplies MurmurHash3 needs per window (8 at k = 10)
+        muls = 4 * (k // 16) + (2 if k % 16 > 0 else 0) + (2 if k % 16 > 8 else 0) + 4  # blocks, tail k1 / k2, two fmix64
+        n_l, ms = timing["sketch_tiles"]
+        ach = q_windows * muls / (ms / n_l / 1e3) / 1e9
+        result["alu_roofline_sketch_tiles"] = {"u64_mul_per_window": muls, "achieved_gmul_per_s": ach,
+                                               "peak_gmul_per_s": aux["device"]["u64_gmul_per_s_measured"],
+                                               "frac": ach / aux["device"]["u64_gmul_per_s_measured"]}
     print(json.dumps(result))
     ctx.close()
     if world > 1:

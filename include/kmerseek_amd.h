@@ -222,6 +222,12 @@ int ks_timing_reset(ks_ctx *ctx);
 /* resolves pending events (synchronizes the stream) and copies up to cap rows; *n = rows available */
 int ks_timing_get(ks_ctx *ctx, ks_kernel_time *rows, uint32_t cap, uint32_t *n);
 
+/* The two ceilings SURVEY.md section 8(d) asks bench.py to print beside the HBM roofline, measured on ctx's device:
+ *   gmul_per_s    - 64-bit integer multiplies per second / 1e9 (MurmurHash3 needs 8 per window for k <= 16),
+ *   copy_gb_per_s - device-to-device hipMemcpy rate, bytes read + bytes written per second / 1e9,
+ *   nominal_gb_per_s - memoryClockRate x memoryBusWidth of the device properties (DDR: x2) / 1e9. */
+int ks_bench_device_rates(ks_ctx *ctx, double *gmul_per_s, double *copy_gb_per_s, double *nominal_gb_per_s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,7 @@ SIGNATURES = {
     "ks_timing_enable": (C.c_int, [_vp, C.c_int]),
     "ks_timing_reset": (C.c_int, [_vp]),
     "ks_timing_get": (C.c_int, [_vp, C.POINTER(ks_kernel_time), C.c_uint32, _u32p]),
+    "ks_bench_device_rates": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -310,6 +310,68 @@ extern "C" int ks_timing_get(ks_ctx *ctx, ks_kernel_time *rows, uint32_t cap, ui
     return KS_OK;
 }
 
+// ---- device ceilings for bench.py: u64 multiply rate, device copy rate ----
+__global__ __launch_bounds__(256) void k_bench_u64_mul(u64 *out, u32 iters) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 a = t * 0x87c37b91114253d5ULL + 1, b = t * 0x4cf5ad432745937fULL + 3, c = t + 5, d = ~t; // four independent chains hide the multiplier latency
+    for (u32 i = 0; i < iters; i++) {
+        a = a * 0x87c37b91114253d5ULL + i; b = b * 0x4cf5ad432745937fULL + i; c = c * 0x87c37b91114253d5ULL + i; d = d * 0x4cf5ad432745937fULL + i; // MurmurHash3 c1, c2
+    }
+    out[t] = a ^ b ^ c ^ d;
+}
+
+extern "C" int ks_bench_device_rates(ks_ctx *ctx, double *gmul_per_s, double *copy_gb_per_s, double *nominal_gb_per_s) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    KS_HIP(ctx, hipEventCreate(&e0));
+    KS_HIP(ctx, hipEventCreate(&e1));
+    int st = KS_OK;
+    float ms = 0;
+    if (gmul_per_s) {
+        const u32 blocks = 256 * 16, iters = 8192;
+        u64 *out = nullptr;
+        st = ks_alloc(ctx, &out, (size_t)blocks * 256);
+        if (st == KS_OK) {
+            hipLaunchKernelGGL(k_bench_u64_mul, dim3(blocks), dim3(256), 0, ctx->stream, out, 64u); // warm-up
+            (void)hipEventRecord(e0, ctx->stream);
+            hipLaunchKernelGGL(k_bench_u64_mul, dim3(blocks), dim3(256), 0, ctx->stream, out, iters);
+            (void)hipEventRecord(e1, ctx->stream);
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                st = ks_fail(ctx, KS_ERR_HIP, "u64-mul micro-benchmark failed");
+            else
+                *gmul_per_s = (double)blocks * 256 * iters * 4 / (ms * 1e-3) / 1e9;
+            ks_pool_free(ctx, out);
+        }
+    }
+    if (st == KS_OK && copy_gb_per_s) {
+        const size_t bytes = (size_t)2 << 30;
+        u8 *a = nullptr, *b = nullptr;
+        st = ks_alloc(ctx, &a, bytes);
+        if (st == KS_OK) st = ks_alloc(ctx, &b, bytes);
+        if (st == KS_OK) {
+            (void)hipMemsetAsync(a, 1, bytes, ctx->stream);
+            (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+            (void)hipEventRecord(e0, ctx->stream);
+            for (int i = 0; i < 4; i++) (void)hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+            (void)hipEventRecord(e1, ctx->stream);
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                st = ks_fail(ctx, KS_ERR_HIP, "copy micro-benchmark failed");
+            else
+                *copy_gb_per_s = 4.0 * 2.0 * (double)bytes / (ms * 1e-3) / 1e9;
+        }
+        ks_pool_free(ctx, a); ks_pool_free(ctx, b);
+    }
+    if (st == KS_OK && nominal_gb_per_s) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "hipGetDeviceProperties failed");
+        else *nominal_gb_per_s = 2.0 * (double)prop.memoryClockRate * 1e3 * ((double)prop.memoryBusWidth / 8.0) / 1e9;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return st;
+}
+
 // ---- host-side pre-step: AminoAcidAmbiguity::validate_and_resolve, src/rust/aminoacid.rs:74-105 ----
 static inline u64 splitmix64(u64 *s) {
     u64 z = (*s += 0x9e3779b97f4a7c15ULL);

@@ -207,6 +207,12 @@ class Context:
     def timing_reset(self):
         self._check(self._L.ks_timing_reset(self._h))
 
+    def device_rates(self) -> Dict[str, float]:
+        """u64-multiply rate, device copy rate and nominal memory bandwidth of this context's GPU (bench.py prints them)."""
+        v = [C.c_double(0) for _ in range(3)]
+        self._check(self._L.ks_bench_device_rates(self._h, *[C.byref(x) for x in v]))
+        return {"u64_gmul_per_s": v[0].value, "copy_gb_per_s": v[1].value, "nominal_gb_per_s": v[2].value}
+
     def timing(self) -> Dict[str, Tuple[int, float]]:
         """{kernel name: (launches, total ms)} from HIP events on the context's stream."""
         n = C.c_uint32(0)
