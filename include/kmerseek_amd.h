@@ -177,6 +177,9 @@ void ks_sketches_free(ks_sketches *s);
  * The host groups triples into KmerInfo{encoded_kmer, original_kmer -> [positions]} (src/rust/kmer.rs:6-12). */
 int ks_kmer_positions(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_offsets,
                       uint32_t n_seqs, const ks_params *params, ks_kmerpos **out);
+/* Same, with the batch already resident in device memory (d_residues 16-byte aligned, n_residues = seq_offsets[n_seqs]). */
+int ks_kmer_positions_device(ks_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_seq_offsets, uint32_t n_seqs,
+                             uint64_t n_residues, const ks_params *params, ks_kmerpos **out);
 uint64_t ks_kmerpos_count(const ks_kmerpos *p);
 int ks_kmerpos_copy_to_host(ks_ctx *ctx, const ks_kmerpos *p, uint32_t *seq, uint32_t *start,
                             uint64_t *hash);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "ks_sketches_union": (C.c_int, [_vp, _vp, _pp]),
     "ks_sketches_free": (None, [_vp]),
     "ks_kmer_positions": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _parp, _pp]),
+    "ks_kmer_positions_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint64, _parp, _pp]),
     "ks_kmerpos_count": (C.c_uint64, [_vp]),
     "ks_kmerpos_copy_to_host": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "ks_kmerpos_free": (None, [_vp]),

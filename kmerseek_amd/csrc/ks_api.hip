@@ -129,111 +129,29 @@ extern "C" void ks_sketches_free(ks_sketches *s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k-mer positions (ProteomeIndex::process_kmers, src/rust/index.rs:749-786)
-// One thread per residue position: sequence by binary search, window bytes through the LUT from
-// global memory, keep iff 0 < h <= max_hash and the window fits; order-preserving compaction by scan.
+// k-mer positions (ProteomeIndex::process_kmers, src/rust/index.rs:749-786): k_kmerpos_tiles in ks_sketch.hip.
 // NOTE: the Rust path hashes the validated sequence as given (no upper-casing inside process_kmers);
 // inputs that reach it are already upper-case, so the LUT's case folding is unobservable.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_kmerpos_flag(const u8 *res, const u64 *offs, u32 n_seqs, u64 n_res, u32 k, u64 seed,
-                                                      u64 max_hash, const u8 *lut, u32 *flags, u64 *hash_tmp, u32 *seq_tmp) {
-    const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_res) return;
-    // sequence containing p: last s with offs[s] <= p
-    u32 lo = 0, hi = n_seqs;
-    while (lo < hi) {
-        u32 mid = lo + ((hi - lo) >> 1);
-        if (offs[mid + 1] > p) hi = mid; else lo = mid + 1;
-    }
-    u32 keep = 0;
-    u64 h = 0;
-    if (lo < n_seqs && p + k <= offs[lo + 1]) {
-        ks_murmur m;
-        m.init(seed);
-        const u8 *w = res + p;
-        const u32 nb = k >> 4, t = k & 15;
-        for (u32 b = 0; b < nb; b++) {
-            u64 k1 = 0, k2 = 0;
-            for (int i = 0; i < 8; i++) { k1 |= (u64)lut[w[16 * b + i]] << (8 * i); k2 |= (u64)lut[w[16 * b + 8 + i]] << (8 * i); }
-            m.block(k1, k2);
-        }
-        if (t) {
-            u64 k1 = 0, k2 = 0;
-            for (u32 i = 0; i < t && i < 8; i++) k1 |= (u64)lut[w[16 * nb + i]] << (8 * i);
-            for (u32 i = 8; i < t; i++) k2 |= (u64)lut[w[16 * nb + i]] << (8 * (i - 8));
-            m.tail(k1, k2, t);
-        }
-        h = m.finish((u64)k);
-        keep = (h != 0 && h <= max_hash) ? 1u : 0u;
-    }
-    flags[p] = keep;
-    hash_tmp[p] = h;
-    seq_tmp[p] = lo;
-}
-
-__global__ __launch_bounds__(256) void k_kmerpos_emit(const u32 *idx, const u64 *hash_tmp, const u32 *seq_tmp, const u64 *offs,
-                                                      u64 n_res, u64 max_hash, u32 *seq, u32 *start, u64 *hash) {
-    const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_res) return;
-    const u64 h = hash_tmp[p];
-    const u32 next = idx[p + 1];
-    if (next != idx[p]) { // kept
-        const u32 o = idx[p];
-        const u32 s = seq_tmp[p];
-        seq[o] = s;
-        start[o] = (u32)(p - offs[s]);
-        hash[o] = h;
-    }
-}
-
 int ks_kmerpos_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, const ks_params *p,
                            ks_kmerpos **out) {
     KS_TRY(ks_check_params(ctx, p));
-    if (n_res >= 0xfffffff0ULL) return ks_fail(ctx, KS_ERR_CAPACITY, "k-mer position batch limited to 2^32 residues");
+    if (((uintptr_t)d_res & 15) != 0) return ks_fail(ctx, KS_ERR_INVALID_ARG, "d_residues must be 16-byte aligned");
+    KS_HIP(ctx, hipSetDevice(ctx->device));
     ks_kmerpos *K = new ks_kmerpos();
     memset(K, 0, sizeof *K);
     K->ctx = ctx;
-    u32 *flags = nullptr, *seq_tmp = nullptr;
-    u64 *hash_tmp = nullptr;
     int st = KS_OK;
-#define KP_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
-#define KP_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
-    if (n_res == 0 || n_seqs == 0) {
-        KP_CHECK(ks_alloc(ctx, &K->d_seq, 1)); KP_CHECK(ks_alloc(ctx, &K->d_start, 1)); KP_CHECK(ks_alloc(ctx, &K->d_hash, 1));
-        goto done;
-    }
-    {
-        KP_CHECK(ks_alloc(ctx, &flags, (size_t)n_res + 1));
-        KP_CHECK(ks_alloc(ctx, &seq_tmp, (size_t)n_res));
-        KP_CHECK(ks_alloc(ctx, &hash_tmp, (size_t)n_res));
-        const u32 grid = (u32)((n_res + 255) / 256);
-        const u64 max_hash = ks_max_hash(p->scaled);
-        ks_timer_begin(ctx, "kmerpos_flag");
-        hipLaunchKernelGGL(k_kmerpos_flag, dim3(grid), dim3(256), 0, ctx->stream, d_res, d_offs, n_seqs, n_res, p->ksize, p->seed,
-                           max_hash, (const u8 *)(ctx->d_lut + 256 * p->moltype), flags, hash_tmp, seq_tmp);
-        ks_timer_end(ctx);
-        KP_HIP(hipGetLastError());
-        // exclusive scan over n_res flags; flags[n_res] receives the total
-        KP_CHECK(ks_scan_u32_inplace(ctx, flags, n_res, flags + n_res));
-        KP_HIP(hipMemcpyAsync(ctx->h_pin, flags + n_res, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-        KP_HIP(hipStreamSynchronize(ctx->stream));
-        K->n = *(u32 *)ctx->h_pin;
-        KP_CHECK(ks_alloc(ctx, &K->d_seq, (size_t)K->n)); KP_CHECK(ks_alloc(ctx, &K->d_start, (size_t)K->n));
-        KP_CHECK(ks_alloc(ctx, &K->d_hash, (size_t)K->n));
-        ks_timer_begin(ctx, "kmerpos_emit");
-        hipLaunchKernelGGL(k_kmerpos_emit, dim3(grid), dim3(256), 0, ctx->stream, (const u32 *)flags, (const u64 *)hash_tmp,
-                           (const u32 *)seq_tmp, d_offs, n_res, max_hash, K->d_seq, K->d_start, K->d_hash);
-        ks_timer_end(ctx);
-        KP_HIP(hipGetLastError());
-        KP_HIP(hipStreamSynchronize(ctx->stream));
-    }
-done:
-    ks_pool_free(ctx, flags); ks_pool_free(ctx, seq_tmp); ks_pool_free(ctx, hash_tmp);
+    // every residue position starts at most one window: n_res bounds the table
+    const size_t cap = (n_res == 0 || n_seqs == 0) ? 1 : (size_t)n_res;
+    st = ks_alloc(ctx, &K->d_seq, cap);
+    if (st == KS_OK) st = ks_alloc(ctx, &K->d_start, cap);
+    if (st == KS_OK) st = ks_alloc(ctx, &K->d_hash, cap);
+    if (st == KS_OK && n_res != 0 && n_seqs != 0)
+        st = ks_kmerpos_tiles_launch(ctx, d_res, d_offs, n_seqs, n_res, p, K->d_seq, K->d_start, K->d_hash, &K->n);
     if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_kmerpos_free(K); return st; }
     *out = K;
     return KS_OK;
-#undef KP_CHECK
-#undef KP_HIP
 }
 
 extern "C" int ks_kmer_positions(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_offsets, uint32_t n_seqs,
@@ -251,6 +169,14 @@ extern "C" int ks_kmer_positions(ks_ctx *ctx, const uint8_t *residues, const uin
     ks_pool_free(ctx, d_res);
     ks_pool_free(ctx, d_offs);
     return st;
+}
+
+extern "C" int ks_kmer_positions_device(ks_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_seq_offsets, uint32_t n_seqs,
+                                        uint64_t n_residues, const ks_params *params, ks_kmerpos **out) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
+    if (n_seqs && (!d_seq_offsets || (n_residues && !d_residues))) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL device buffer");
+    return ks_kmerpos_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, params, out);
 }
 
 extern "C" uint64_t ks_kmerpos_count(const ks_kmerpos *p) { return p ? p->n : 0; }

@@ -183,6 +183,8 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
 int ks_join_pbits(u64 n_postings);
 // multiplier of ks_join_prefix (ks_device.h) for a join on pbits prefix bits of hashes kept below max_hash
 u32 ks_join_prefix_mul(int pbits, u64 max_hash);
+int ks_kmerpos_tiles_launch(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, const ks_params *p, u32 *d_seq,
+                            u32 *d_start, u64 *d_hash, u64 *n_out);
 int ks_kmerpos_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,
                            const ks_params *p, ks_kmerpos **out);
 int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out);

@@ -812,6 +812,238 @@ __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u64 *o
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k-mer position table (ProteomeIndex::process_kmers, src/rust/index.rs:749-786; KmerInfo of kmer.rs:6-12):
+// (sequence, start, hash) of every kept window, ordered by (sequence, start), in ONE pass.
+// A tile is a fixed range of KP_R residue positions (windows of any sequence: there is no per-sequence sort here, so
+// no deferral): residues staged through the LUT like the sketch kernel, 8 windows hashed per thread from LDS, kept
+// windows compacted in position order, and the tile's slice of the output found by the same decoupled look-back
+// (ticket-ordered tiles, 8-byte {flag, value} status words) the sketch kernel uses for its CSR.
+// Not fused into k_sketch_tiles on purpose: that kernel is instruction-bound at its register limit (78 of 80 VGPRs),
+// and this one re-hashes at the rate the 16 B per window of output allow anyway.
+// ---------------------------------------------------------------------------------------------
+#define KP_R SK_TILE
+struct kp_args {
+    const u8 *res;
+    const u64 *offs;
+    const u8 *lut;
+    const u32 *tile_first;          // first sequence whose END lies beyond the tile's first position
+    unsigned long long *tile_status;
+    u32 *ticket;                    // [0] tile ids, [1] look-back gave up
+    u64 *total;                     // kept windows of the whole batch (written by the last tile)
+    u32 *out_seq, *out_start;
+    u64 *out_hash;
+    u64 n_res, max_hash, seed;
+    u32 n_seqs, k, n_tiles;
+};
+
+__global__ __launch_bounds__(256) void k_kmerpos_plan(const u64 *offs, u32 n_seqs, u32 n_tiles, u32 *tile_first) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    // first s with offs[s + 1] > t * KP_R
+    tile_first[t] = sk_lower_bound(offs + 1, 0, n_seqs, (u64)t * KP_R + 1);
+}
+
+__global__ __launch_bounds__(SK_THREADS) void k_kmerpos_tiles(kp_args A) {
+    __shared__ __attribute__((aligned(16))) u64 res_w[(SK_TILE + SK_PAD) / 8];
+    __shared__ __attribute__((aligned(16))) u64 stage[SK_TILE]; // compacted output staging: hashes, then (seq, start)
+    __shared__ u32 lend[SK_SEQ_CAP + 2]; // local END of the tile's sequences (clamped)
+    __shared__ u8 lut_s[256];
+    __shared__ u32 scan_smem[SK_THREADS / 64 + 1];
+    __shared__ u32 tile_s;
+    __shared__ unsigned long long base_s;
+    const u32 tid = threadIdx.x;
+    constexpr u32 NCH = (SK_TILE + SK_PAD) / 16;
+    u32 ticket_v = 0;
+    if (tid == 0) ticket_v = atomicAdd(&A.ticket[0], 1u);
+    if (tid < 256) lut_s[tid] = A.lut[tid];
+    if (tid == 0) tile_s = ticket_v;
+    __syncthreads();
+    const u32 tile = tile_s;
+    const u64 g0 = (u64)tile * KP_R;
+    uint4 rv = make_uint4(0, 0, 0, 0);
+    if (tid < NCH) {
+        const u64 g = g0 + (u64)tid * 16;
+        if (g + 16 <= A.n_res) {
+            rv = *(const uint4 *)(A.res + g);
+        } else {
+            u32 t[4] = {0, 0, 0, 0};
+            for (u32 b = 0; b < 16 && g + b < A.n_res; b++) t[b >> 2] |= (u32)A.res[g + b] << (8 * (b & 3));
+            rv = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+    }
+    const u32 s_first = A.tile_first[tile];
+    u32 s_last = A.tile_first[tile + 1]; // the sequence that holds the next tile's first position also ends here or later
+    if (s_last >= A.n_seqs) s_last = A.n_seqs ? A.n_seqs - 1 : 0;
+    const u32 ns = s_first < A.n_seqs ? s_last - s_first + 1 : 0;
+    const bool in_lds = ns <= SK_SEQ_CAP;
+    if (in_lds)
+        for (u32 i = tid; i < ns; i += SK_THREADS) {
+            const u64 v = A.offs[s_first + i + 1] - g0; // ends beyond the tile's first position: never negative
+            lend[i] = v > 0x7fffffffULL ? 0x7fffffffu : (u32)v;
+        }
+    if (tid < NCH) {
+        const u32 in[4] = {rv.x, rv.y, rv.z, rv.w};
+        u32 o[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            o[d] = (u32)lut_s[in[d] & 255u] | ((u32)lut_s[(in[d] >> 8) & 255u] << 8) |
+                   ((u32)lut_s[(in[d] >> 16) & 255u] << 16) | ((u32)lut_s[in[d] >> 24] << 24);
+        *(uint4 *)((u8 *)res_w + (size_t)tid * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    auto end_of = [&](u32 s) -> u32 { // local end of sequence s (s_first <= s <= s_last)
+        if (in_lds) return lend[s - s_first];
+        const u64 v = A.offs[s + 1] - g0;
+        return v > 0x7fffffffULL ? 0x7fffffffu : (u32)v;
+    };
+
+    const u32 q0 = tid * SK_E;
+    u64 h[SK_E];
+    u32 sq[SK_E]; // sequence of a kept window, ~0 = not kept
+    u32 n_keep = 0;
+#pragma unroll
+    for (int i = 0; i < SK_E; i++) { h[i] = 0; sq[i] = 0xffffffffu; }
+    if (ns && g0 + q0 < A.n_res) {
+        // the sequence that holds position q0: first one (from s_first) whose end lies beyond q0
+        u32 lo = s_first, hi = s_last;
+        while (lo < hi) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            if (end_of(mid) > q0) hi = mid; else lo = mid + 1;
+        }
+        u32 s = lo, e = end_of(s);
+        const u64 *wl = res_w + tid;
+        h[0] = sk_hash_window<0>(wl, A.k, A.seed);
+        h[1] = sk_hash_window<1>(wl, A.k, A.seed);
+        h[2] = sk_hash_window<2>(wl, A.k, A.seed);
+        h[3] = sk_hash_window<3>(wl, A.k, A.seed);
+        h[4] = sk_hash_window<4>(wl, A.k, A.seed);
+        h[5] = sk_hash_window<5>(wl, A.k, A.seed);
+        h[6] = sk_hash_window<6>(wl, A.k, A.seed);
+        h[7] = sk_hash_window<7>(wl, A.k, A.seed);
+#pragma unroll
+        for (int i = 0; i < SK_E; i++) {
+            const u32 p = q0 + i;
+            while (s < s_last && p >= e) { s++; e = end_of(s); }
+            // offsets are cumulative, so p lies inside sequence s as soon as p < e; the window must fit before e
+            const bool keep = p < e && p + A.k <= e && h[i] != 0 && h[i] <= A.max_hash;
+            if (keep) { sq[i] = s; n_keep++; }
+        }
+    }
+    u32 total;
+    const u32 ex = ks_block_excl_scan(n_keep, scan_smem, &total);
+    // ---- decoupled look-back over the tiles' kept counts (see k_sketch_tiles)
+    if (tid == 0)
+        __hip_atomic_store(&A.tile_status[tile], (tile == 0 ? SK_FLAG_PRE : SK_FLAG_AGG) | (u64)total, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        u64 excl = 0;
+        if (tile > 0) {
+            i64 idx = (i64)tile - 1;
+            bool done = false;
+            u32 spins = 0;
+            while (!done) {
+                const i64 mine = idx - (i64)tid;
+                u64 v = SK_FLAG_PRE;
+                if (mine >= 0) {
+                    v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((v >> 62) == 0 && spins < SK_SPIN_MAX) {
+                        __builtin_amdgcn_s_sleep(1);
+                        v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        spins++;
+                    }
+                }
+                if ((v >> 62) == 0) { A.ticket[1] = 1; v = SK_FLAG_PRE; }
+                const u64 is_pre = __ballot((v >> 62) == 2);
+                const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
+                u64 contrib = tid <= first ? (v & SK_VAL_MASK) : 0;
+                for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+                excl += contrib;
+                if (is_pre) done = true; else idx -= 64;
+            }
+            if (tid == 0)
+                __hip_atomic_store(&A.tile_status[tile], SK_FLAG_PRE | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) {
+            base_s = excl;
+            if (tile == A.n_tiles - 1) *A.total = excl + total;
+        }
+    }
+    __syncthreads();
+    // kept windows leave through LDS in compacted order, so the three output streams are written as whole cache lines
+    // (per-thread runs of <= 8 entries would touch 64 different 32-byte sectors per store instruction)
+    const u64 base = base_s;
+    {
+        u32 o = ex;
+#pragma unroll
+        for (int i = 0; i < SK_E; i++)
+            if (sq[i] != 0xffffffffu) stage[o++] = h[i];
+    }
+    __syncthreads();
+    for (u32 i = tid; i < total; i += SK_THREADS) A.out_hash[base + i] = stage[i];
+    __syncthreads();
+    {
+        u32 *st_seq = (u32 *)stage, *st_start = st_seq + SK_TILE;
+        u32 o = ex;
+#pragma unroll
+        for (int i = 0; i < SK_E; i++)
+            if (sq[i] != 0xffffffffu) {
+                st_seq[o] = sq[i];
+                st_start[o] = (u32)(g0 + q0 + i - A.offs[sq[i]]);
+                o++;
+            }
+        __syncthreads();
+        for (u32 i = tid; i < total; i += SK_THREADS) {
+            A.out_seq[base + i] = st_seq[i];
+            A.out_start[base + i] = st_start[i];
+        }
+    }
+}
+
+// d_seq / d_start / d_hash are sized by the batch's window count (an upper bound on the kept windows)
+int ks_kmerpos_tiles_launch(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, const ks_params *p, u32 *d_seq,
+                            u32 *d_start, u64 *d_hash, u64 *n_out) {
+    const u64 n_tiles64 = (n_res + KP_R - 1) / KP_R;
+    if (n_tiles64 > 0x7ffffff0ULL) return ks_fail(ctx, KS_ERR_INVALID_ARG, "batch too large");
+    const u32 n_tiles = (u32)n_tiles64;
+    u32 *tile_first = nullptr, *ticket = nullptr;
+    unsigned long long *status = nullptr;
+    u64 *total = nullptr;
+    int st = ks_alloc(ctx, &tile_first, (size_t)n_tiles + 1);
+    if (st == KS_OK) st = ks_alloc(ctx, (u64 **)&status, (size_t)n_tiles);
+    if (st == KS_OK) st = ks_alloc(ctx, &ticket, 2);
+    if (st == KS_OK) st = ks_alloc(ctx, &total, 1);
+    if (st == KS_OK) {
+        (void)hipMemsetAsync(status, 0, (size_t)n_tiles * sizeof(u64), ctx->stream);
+        (void)hipMemsetAsync(ticket, 0, 2 * sizeof(u32), ctx->stream);
+        (void)hipMemsetAsync(total, 0, sizeof(u64), ctx->stream);
+        ks_timer_begin(ctx, "kmerpos_plan");
+        hipLaunchKernelGGL(k_kmerpos_plan, dim3((n_tiles + 256) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, n_tiles, tile_first);
+        ks_timer_end(ctx);
+        kp_args A;
+        memset(&A, 0, sizeof A);
+        A.res = d_res; A.offs = d_offs; A.lut = ctx->d_lut + 256 * p->moltype; A.tile_first = tile_first;
+        A.tile_status = status; A.ticket = ticket; A.total = total; A.out_seq = d_seq; A.out_start = d_start; A.out_hash = d_hash;
+        A.n_res = n_res; A.max_hash = ks_max_hash(p->scaled); A.seed = p->seed; A.n_seqs = n_seqs; A.k = p->ksize; A.n_tiles = n_tiles;
+        ks_timer_begin(ctx, "kmerpos_tiles");
+        hipLaunchKernelGGL(k_kmerpos_tiles, dim3(n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
+        ks_timer_end(ctx);
+        if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "k-mer position launch failed");
+    }
+    if (st == KS_OK) {
+        if (hipMemcpyAsync(ctx->h_pin, total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(ctx->h_pin + 1, ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            st = ks_fail(ctx, KS_ERR_HIP, "k-mer position status read failed");
+        else if (((u32 *)(ctx->h_pin + 1))[1] != 0)
+            st = ks_fail(ctx, KS_ERR_HIP, "k-mer positions: look-back gave up waiting for a predecessor tile");
+        else
+            *n_out = ctx->h_pin[0];
+    }
+    ks_pool_free(ctx, tile_first); ks_pool_free(ctx, status); ks_pool_free(ctx, ticket); ks_pool_free(ctx, total);
+    return st;
+}
+
 // out[0] = k-mer windows, out[1] = longest sequence, out[2] = long sequences, out[4 + c] = medium (deferred but
 // tile-sized) sequences under tile stride sk_r_cand[c]
 __global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, u32 k, u64 *out) {

@@ -188,6 +188,24 @@ class Context:
             self._L.ks_kmerpos_free(out)
         return seq, start, h
 
+    def kmer_positions_device(self, d_residues: int, d_offsets: int, n_seqs: int, n_residues: int, ksize: int, scaled: int,
+                              moltype: str, seed: int = SEED, fetch: bool = True):
+        """Same from device-resident buffers; fetch=False returns only the number of kept windows (table stays on the GPU
+        and is freed) — what bench / profiling runs use."""
+        p = make_params(ksize, scaled, moltype, seed)
+        out = C.c_void_p()
+        self._check(self._L.ks_kmer_positions_device(self._h, C.c_void_p(d_residues), C.c_void_p(d_offsets), n_seqs, n_residues,
+                                                     C.byref(p), C.byref(out)))
+        try:
+            n = int(self._L.ks_kmerpos_count(out))
+            if not fetch:
+                return n
+            seq = np.zeros(n, np.uint32); start = np.zeros(n, np.uint32); h = np.zeros(n, np.uint64)
+            self._check(self._L.ks_kmerpos_copy_to_host(self._h, out, _ptr(seq), _ptr(start), _ptr(h)))
+        finally:
+            self._L.ks_kmerpos_free(out)
+        return seq, start, h
+
     # ---- index / search ----
     def index_build(self, targets: "Sketches") -> "Index":
         out = C.c_void_p()

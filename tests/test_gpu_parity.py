@@ -178,6 +178,45 @@ def test_kmer_positions_vs_oracle(ctx):
         assert seq_i.tolist() == ws and start.tolist() == wst and h.tolist() == wh
 
 
+def _oracle_positions(res, offs, k, scaled, mol):
+    o, mins, _ = oracle.sketch_batch(res, offs, k, scaled, mol, n_threads=8)
+    ws, wst, wh = [], [], []
+    for i in range(len(offs) - 1):
+        seq = bytes(res[int(offs[i]):int(offs[i + 1])])
+        st, hh = oracle.kmer_positions(seq, k, mol, mins[int(o[i]):int(o[i + 1])])
+        ws.append(np.full(len(st), i, np.uint32)); wst.append(st); wh.append(hh)
+    return np.concatenate(ws), np.concatenate(wst), np.concatenate(wh)
+
+
+def test_kmer_positions_ragged_and_tile_edges(ctx):
+    """The position kernel cuts the batch into fixed 4096-residue tiles regardless of sequence boundaries: sequences
+    that straddle tiles, runs of empty / shorter-than-k sequences, more sequences in one tile than its LDS boundary
+    table holds, windows that start in one tile and end in the next, large k."""
+    rng = np.random.default_rng(17)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    lens = [0, 3, 4090, 0, 0, 12, 9000, 1, 5, 4096, 4097, 2, 0, 40000, 7]
+    lens += [int(x) for x in rng.integers(0, 9, 900)]          # ~4 residues each: > 254 sequences inside one tile
+    lens += [int(x) for x in rng.integers(100, 600, 60)] + [0, 0, 4095, 1, 8190, 0]
+    offs = np.zeros(len(lens) + 1, np.uint64)
+    np.cumsum(np.array(lens, np.uint64), out=offs[1:])
+    res = rng.choice(aa, size=int(offs[-1])).astype(np.uint8)
+    for k, scaled, mol in ((5, 1, "protein"), (10, 1, "protein"), (21, 2, "hp"), (64, 1, "dayhoff"), (100, 1, "protein")):
+        got = ctx.kmer_positions(res, offs, k, scaled, mol)
+        want = _oracle_positions(res, offs, k, scaled, mol)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+        # the device-resident entry point gives the same table
+        d_res, d_off = ctx.to_device(res), ctx.to_device(offs)
+        got_d = ctx.kmer_positions_device(d_res.ptr, d_off.ptr, len(lens), len(res), k, scaled, mol)
+        for g, w in zip(got_d, want):
+            assert np.array_equal(g, w)
+    # nothing to report
+    s, st, h = ctx.kmer_positions(np.zeros(0, np.uint8), np.zeros(4, np.uint64), 5, 1, "protein")
+    assert len(s) == 0 and len(st) == 0 and len(h) == 0
+    s, st, h = ctx.kmer_positions(res[:3], np.array([0, 3], np.uint64), 5, 1, "protein")
+    assert len(s) == 0
+
+
 @pytest.mark.parametrize("k,scaled,mol,nt,nq", [
     (7, 1, "protein", 2000, 1500), (16, 5, "dayhoff", 3000, 3000), (24, 5, "hp", 2500, 2500),
     (5, 1, "hp", 120, 90),  # saturated alphabet: every pair shares hashes, thousands of matches per hash
