@@ -50,6 +50,26 @@ int ksh_index_save_state(ksh_index *ix, char *err, size_t err_cap);
 int ksh_index_load(const char *path, int device, ksh_index **out, char *err, size_t err_cap);
 void ksh_string_free(char *s);
 
+/* ---- pipelined FASTA ingest (kmerseek_amd/csrc/ks_ingest.cpp) -------------------------------------
+ * FASTA file (plain or gzip) -> the sketches of all its records as one host CSR, with the stages running concurrently:
+ * reader thread -> validate / pack threads into pinned buffers -> H2D on a copy stream -> ks_sketch_batch_device + D2H.
+ *   validate = 1: upper-case + AminoAcidAmbiguity::validate_and_resolve per record, first bad residue aborts with the
+ *                 reference's message (the Rust index path: src/rust/index.rs:984-1016, aminoacid.rs:74-105);
+ *   validate = 0: raw record bytes, as sourmash_plugin_branchwater.do_manysketch takes them (src/python/kmerseek/sketch.py:28-40).
+ *   batch_residues: residues per device batch (0 = 16 MiB); pipeline = 0 runs the stages back to back (baseline). */
+typedef struct ksh_fasta_sketches ksh_fasta_sketches;
+int ksh_sketch_fasta(const char *fasta_path, uint32_t ksize, uint32_t scaled, const char *moltype, int validate, int device,
+                     uint64_t batch_residues, int pipeline, ksh_fasta_sketches **out, char *err, size_t err_cap);
+uint64_t ksh_fs_n_records(const ksh_fasta_sketches *r);
+uint64_t ksh_fs_n_hashes(const ksh_fasta_sketches *r);
+const uint64_t *ksh_fs_offsets(const ksh_fasta_sketches *r); /* n_records + 1 */
+const uint64_t *ksh_fs_hashes(const ksh_fasta_sketches *r);
+const uint32_t *ksh_fs_abunds(const ksh_fasta_sketches *r);
+const char *ksh_fs_names(ksh_fasta_sketches *r, uint64_t *len); /* record ids joined by '\n' */
+/* seconds[6] = wall, reader busy, validate/pack busy, H2D busy, device (sketch + D2H to pinned) busy, collector busy */
+void ksh_fs_stats(const ksh_fasta_sketches *r, uint64_t *n_residues, uint64_t *n_windows, uint64_t *n_batches, double *seconds);
+void ksh_fs_free(ksh_fasta_sketches *r);
+
 #ifdef __cplusplus
 }
 #endif

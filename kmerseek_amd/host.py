@@ -41,6 +41,17 @@ HOST_SIGNATURES = {
     "ksh_index_save_state": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "ksh_index_load": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
     "ksh_string_free": (None, [C.c_void_p]),
+    "ksh_sketch_fasta": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_int,
+                                   C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "ksh_fs_n_records": (C.c_uint64, [C.c_void_p]),
+    "ksh_fs_n_hashes": (C.c_uint64, [C.c_void_p]),
+    "ksh_fs_offsets": (C.POINTER(C.c_uint64), [C.c_void_p]),
+    "ksh_fs_hashes": (C.POINTER(C.c_uint64), [C.c_void_p]),
+    "ksh_fs_abunds": (C.POINTER(C.c_uint32), [C.c_void_p]),
+    "ksh_fs_names": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "ksh_fs_stats": (None, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                            C.POINTER(C.c_double)]),
+    "ksh_fs_free": (None, [C.c_void_p]),
 }
 
 _bound = None
@@ -278,3 +289,33 @@ class PyProteomeIndex:
 
     def __init__(self, ksize: int, scaled: int, moltype, db_path: str):
         self.index = ProteomeIndex(db_path, ksize, scaled, str(moltype), False)
+
+
+def sketch_fasta(path, ksize: int, scaled: int, moltype: str, validate: bool = False, device: int = 0,
+                 batch_residues: int = 0, pipeline: bool = True):
+    """Pipelined FASTA ingest (kmerseek_amd/csrc/ks_ingest.cpp): (names, offsets u64[n+1], hashes u64[], abunds u32[], stats)
+    for every record of a plain / gzip FASTA file.  validate=False hashes the raw record bytes as manysketch does
+    (src/python/kmerseek/sketch.py:28-40); validate=True is the Rust index path (upper-case + validate_and_resolve)."""
+    import numpy as np
+    L = _host()
+    h = C.c_void_p()
+    _call(L.ksh_sketch_fasta, str(path).encode(), ksize, scaled, str(moltype).encode(), 1 if validate else 0, device,
+          int(batch_residues), 1 if pipeline else 0, C.byref(h))
+    try:
+        n = int(L.ksh_fs_n_records(h))
+        nh = int(L.ksh_fs_n_hashes(h))
+        offsets = np.ctypeslib.as_array(L.ksh_fs_offsets(h), shape=(n + 1,)).copy()
+        hashes = np.ctypeslib.as_array(L.ksh_fs_hashes(h), shape=(nh,)).copy() if nh else np.zeros(0, np.uint64)
+        abunds = np.ctypeslib.as_array(L.ksh_fs_abunds(h), shape=(nh,)).copy() if nh else np.zeros(0, np.uint32)
+        ln = C.c_uint64(0)
+        p = L.ksh_fs_names(h, C.byref(ln))
+        blob = C.string_at(p, ln.value).decode() if n else ""
+        names = blob.split("\n") if n else []
+        nr, nw, nb = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        sec = (C.c_double * 6)()
+        L.ksh_fs_stats(h, C.byref(nr), C.byref(nw), C.byref(nb), sec)
+        stats = {"residues": nr.value, "windows": nw.value, "batches": nb.value, "wall_s": sec[0], "read_s": sec[1],
+                 "pack_s": sec[2], "h2d_s": sec[3], "device_s": sec[4], "collect_s": sec[5]}
+    finally:
+        L.ksh_fs_free(h)
+    return names, offsets, hashes, abunds, stats

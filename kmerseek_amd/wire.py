@@ -125,20 +125,15 @@ def _make_sigfile(fasta: str, moltype: str, ksize: int, scaled: int) -> str:
 
 
 def sketch(fasta: str, moltype: str, ksize: int, scaled: int, ctx: Optional[Context] = None) -> str:
-    own = ctx is None
-    ctx = ctx or Context(0)
-    try:
-        sigfile = _make_sigfile(fasta, moltype, ksize, scaled)
-        _make_manysketch_csv(fasta)
-        recs = read_fasta(fasta)
-        from .engine import pack
-        res, offs = pack([s for _, s in recs])
-        o, m, a = ctx.sketch_batch(res, offs, ksize, scaled, moltype).to_host()
-        write_sig_zip(sigfile, [n for n, _ in recs], o, m, a, ksize, scaled, moltype, os.path.abspath(fasta))
-        return sigfile
-    finally:
-        if own:
-            ctx.close()
+    """sketch() of src/python/kmerseek/sketch.py:28-40.  The records go through the native pipelined ingest
+    (csrc/ks_ingest.cpp: parse, pinned staging, H2D and the sketch kernels overlap); `ctx` only picks the device."""
+    from . import host
+    sigfile = _make_sigfile(fasta, moltype, ksize, scaled)
+    _make_manysketch_csv(fasta)
+    names, o, m, a, _ = host.sketch_fasta(fasta, ksize, scaled, moltype, validate=False,
+                                          device=ctx.device if ctx is not None and hasattr(ctx, "device") else 0)
+    write_sig_zip(sigfile, names, o, m, a, ksize, scaled, moltype, os.path.abspath(fasta))
+    return sigfile
 
 
 # ---------------------------------------------------------------------------------------------------------

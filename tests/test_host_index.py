@@ -271,3 +271,64 @@ def test_search_extract_kmers_equals_expected(tmp_path, search_expected):
     assert "match: HQQEQEAEGVAAPADP (42-58)" in printed
     # rows come out sorted by (query_start, query_end), as the reference prints them
     assert [r["query_start"] for r in rows] == sorted(r["query_start"] for r in rows)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# pipelined FASTA ingest: same sketches as one batched call, whatever the batching
+# ---------------------------------------------------------------------------------------------------------
+def _batch_sketch(path, k, scaled, mol):
+    recs = wire.read_fasta(str(path))
+    res, offs = ks.pack([s for _, s in recs])
+    ctx = ks.Context(0)
+    try:
+        o, m, a = ctx.sketch_batch(res, offs, k, scaled, mol).to_host()
+    finally:
+        ctx.close()
+    return [n for n, _ in recs], o, m, a
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fname", [BCL2, "ced9.fasta", "test_compression.fasta"])
+def test_sketch_fasta_pipeline_equals_batch_sketch(fname):
+    path = os.path.join(GOLDEN, fname)
+    for k, scaled, mol in ((10, 1, "protein"), (16, 5, "hp")):
+        names, o, m, a = _batch_sketch(path, k, scaled, mol)
+        for pipeline, batch in ((True, 0), (True, 700), (False, 700), (True, 1)):
+            n2, o2, m2, a2, stats = host.sketch_fasta(path, k, scaled, mol, validate=False, batch_residues=batch, pipeline=pipeline)
+            assert n2 == names
+            assert np.array_equal(o2, o) and np.array_equal(m2, m) and np.array_equal(a2, a)
+            assert stats["residues"] == sum(len(s) for _, s in wire.read_fasta(path))
+            if batch == 1:
+                assert stats["batches"] == len(names)  # one record per device batch
+
+
+@pytest.mark.gpu
+def test_sketch_fasta_validate_path_and_errors(tmp_path):
+    f = tmp_path / "mixed.fasta"
+    f.write_text(">lower\nplantandanimalgenqmes\n>stop\nLIVINGALIVE*IGNORED\n>wrapped\nACDEFGHIKL\nMNPQRSTVWY\n\n>empty\n>last\nMKVLAAGIVGLCAK\r\n")
+    names, o, m, a, stats = host.sketch_fasta(f, 5, 1, "protein", validate=True, batch_residues=16)
+    assert names == ["lower", "stop", "wrapped", "empty", "last"]
+    want = [b"PLANTANDANIMALGENQMES", b"LIVINGALIVE*", b"ACDEFGHIKLMNPQRSTVWY", b"", b"MKVLAAGIVGLCAK"]
+    res, offs = ks.pack(want)
+    wo, wm, wa = oracle.sketch_batch(res, offs, 5, 1, "protein")
+    assert np.array_equal(o, wo) and np.array_equal(m, wm) and np.array_equal(a, wa)
+    # raw (manysketch) mode hashes the bytes as given: lower case is folded by the hash LUT, '*' is just a residue
+    names, o, m, a, _ = host.sketch_fasta(f, 5, 1, "protein", validate=False)
+    res, offs = ks.pack([b"plantandanimalgenqmes", b"LIVINGALIVE*IGNORED", b"ACDEFGHIKLMNPQRSTVWY", b"", b"MKVLAAGIVGLCAK"])
+    wo, wm, wa = oracle.sketch_batch(res, offs, 5, 1, "protein")
+    assert np.array_equal(o, wo) and np.array_equal(m, wm) and np.array_equal(a, wa)
+    bad = tmp_path / "bad.fasta"
+    bad.write_text(">ok1\nPLANTANDANIMALGENQMES\n>bad\nPLANTANDANIMALGEN1MES\n")
+    with pytest.raises(RuntimeError) as e:
+        host.sketch_fasta(bad, 5, 1, "protein", validate=True)
+    assert "Invalid amino acid '1' found at position 18" in str(e.value)
+    with pytest.raises(RuntimeError) as e:
+        host.sketch_fasta(tmp_path / "missing.fasta", 5, 1, "protein")
+    assert "cannot open" in str(e.value)
+    with pytest.raises(RuntimeError):
+        host.sketch_fasta(f, 5, 1, "nucleotide")
+    nohdr = tmp_path / "nohdr.fasta"
+    nohdr.write_text("ACDEFG\n>x\nACDEFG\n")
+    with pytest.raises(RuntimeError) as e:
+        host.sketch_fasta(nohdr, 5, 1, "protein")
+    assert "does not start with '>'" in str(e.value)
