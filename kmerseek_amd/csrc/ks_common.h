@@ -51,6 +51,8 @@ struct ks_ctx {
     bool t_open = false; // the last ks_timer_begin recorded a start event
     // small pinned host scratch for counters read back from the device
     u64 *h_pin = nullptr; // 64 x u64
+    // matched posting pairs of recent searches (+ slack): sizes the next search's match list so the join runs once
+    u64 pair_cap_hint = 0;
     // encode LUTs (3 x 256 bytes) in device memory
     u8 *d_lut = nullptr;
 };

@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void k_pair_reduce(const u64 *keys, const u32 
         if (lane >= (u32)d && orow == row) { w += ow; c += oc; }
     }
     const u32 nrow = __shfl_down(row, 1, 64);
+    // (plain stores for rows that sit wholly inside a wave were measured slower than these fire-and-forget adds)
     if (live && (lane == 63 || nrow != row)) {
         atomicAdd(&isect[row], c);
         atomicAdd(&nw[row], (unsigned long long)w);
@@ -352,6 +353,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         SE_HIP(hipGetLastError());
         const bool pre = q->part_keys && q->part_pbits == pbits && q->part_K == pfxK && pbits > 0;
         u64 cap = n_q < (1u << 20) ? (1u << 20) : n_q;
+        if (ctx->pair_cap_hint > cap) cap = ctx->pair_cap_hint; // a workload that matched heavily last time will again
         u64 n_pairs = 0;
         // way 0: histogram-free bucket scatter of the sketch kernel's regions (may overflow on skewed hashes);
         // way 1: the dense, always-correct partition
@@ -445,6 +447,10 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
             ks_pool_free(ctx, pk0); ks_pool_free(ctx, pv0); pk0 = nullptr; pv0 = nullptr;
         }
         H->n_pair_instances = n_pairs;
+        {
+            const u64 want = n_pairs + n_pairs / 8;
+            ctx->pair_cap_hint = want > ctx->pair_cap_hint / 2 ? want : ctx->pair_cap_hint / 2; // follows growth at once, decays slowly
+        }
         if (n_pairs == 0) {
             SE_CHECK(ks_alloc(ctx, &H->d_qid, 1)); SE_CHECK(ks_alloc(ctx, &H->d_tid, 1));
             SE_CHECK(ks_alloc(ctx, &H->d_isect, 1)); SE_CHECK(ks_alloc(ctx, &H->d_nw, 1));
