@@ -56,6 +56,10 @@ extern "C" void ks_debug_read_stamps(unsigned long long *out, int reset) {
     for (int i = 0; i < 16; i++) { out[i] = 0; for (int s = 0; s < SK_STAMP_SLOTS; s++) out[i] += host[s][i]; }
     if (reset) { memset(host, 0, sizeof host); (void)hipMemcpyToSymbol(HIP_SYMBOL(sk_stamp_acc), host, sizeof host); }
 }
+#elif defined(SK_STOP_AFTER)
+// Diagnostic build only (-DSK_STOP_AFTER=n): every workgroup returns after phase n, so a counter pass over variants
+// n = 0..8 gives the cumulative instruction mix by phase (tools/phase_counters.py).  The output is garbage.
+#define SK_STAMP_AT(i) do { if ((i) == SK_STOP_AFTER) return; } while (0)
 #else
 #define SK_STAMP_AT(i) do { } while (0)
 #endif
@@ -351,7 +355,8 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
         if (tid == SK_THREADS - 1) cnt[SK_TILE / 2] = total | (total << 16);
     }
     __syncthreads();
-    auto bstart = [&](u32 b) -> u32 { return (cnt[b >> 1] >> ((b & 1u) * 16u)) & 0xffffu; };
+    // (the packed 16-bit starts read as a u16 array: one ds_read_u16 instead of read + shift + mask)
+    auto bstart = [&](u32 b) -> u32 { return ((const u16 *)cnt)[b]; };
 
     SK_STAMP_AT(3);
     // ---- phase 4: scatter kept hashes into bucket order
