@@ -1077,13 +1077,23 @@ __global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, 
 #pragma unroll
         for (int c = 0; c < SK_NR; c++) nd[c] += __shfl_down(nd[c], d, 64);
     }
+    // one set of device atomics per WORKGROUP (they all hit the same few words: per wave they were the whole run time)
+    __shared__ u64 red[4][3 + SK_NR];
+    const u32 wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd((unsigned long long *)&out[0], (unsigned long long)w);
-        atomicMax((unsigned long long *)&out[1], (unsigned long long)mx);
-        if (nl) atomicAdd((unsigned long long *)&out[2], (unsigned long long)nl);
+        red[wave][0] = w; red[wave][1] = mx; red[wave][2] = nl;
 #pragma unroll
-        for (int c = 0; c < SK_NR; c++)
-            if (nd[c]) atomicAdd((unsigned long long *)&out[4 + c], (unsigned long long)nd[c]);
+        for (int c = 0; c < SK_NR; c++) red[wave][3 + c] = nd[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 + SK_NR) {
+        const u32 j = threadIdx.x;
+        u64 v = red[0][j];
+        for (u32 q = 1; q < 4; q++) v = j == 1 ? (red[q][j] > v ? red[q][j] : v) : v + red[q][j];
+        if (v) {
+            if (j == 1) atomicMax((unsigned long long *)&out[1], (unsigned long long)v);
+            else atomicAdd((unsigned long long *)&out[j == 0 ? 0 : (j == 2 ? 2 : 4 + (j - 3))], (unsigned long long)v);
+        }
     }
 }
 
@@ -1128,7 +1138,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         SK_CHECK(ks_alloc(ctx, &d_stats, 4 + SK_NR));
         SK_HIPCHECK(hipMemsetAsync(d_stats, 0, (4 + SK_NR) * sizeof(u64), ctx->stream));
         u32 g = (n_seqs + 1023) / 1024;
-        if (g > 2048) g = 2048;
+        if (g > 512) g = 512;
         ks_timer_begin(ctx, "seq_stats");
         hipLaunchKernelGGL(k_seq_stats, dim3(g), dim3(256), 0, ctx->stream, d_offs, n_seqs, p->ksize, d_stats);
         ks_timer_end(ctx);
