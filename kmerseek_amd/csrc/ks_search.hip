@@ -119,6 +119,9 @@ done:
 #define JN_E 12
 #endif
 //                     JN_E query postings per thread per round: 12 independent fixed-trip LDS searches in flight
+#ifndef JN_FILLU
+#define JN_FILLU 6
+#endif
 #ifndef JN_CAP
 #define JN_CAP 6144
 #endif
@@ -202,7 +205,21 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
     if (qs == qe || ts == te) return;
     for (u64 c0 = ts; c0 < te; c0 += JN_CAP) {
         const u32 n = (u32)((te - c0) < JN_CAP ? (te - c0) : JN_CAP);
-        for (u32 i = tid; i < n; i += JN_THREADS) lk[i] = ikeys[c0 + i];
+        // JN_FILLU loads of a thread are in flight before their LDS stores (a plain loop waits out one memory latency
+        // per 512 keys; all JN_CAP / JN_THREADS at once costs the registers of a third workgroup per CU)
+        for (u32 i0 = 0; i0 < n; i0 += JN_THREADS * JN_FILLU) {
+            u64 kk[JN_FILLU];
+#pragma unroll
+            for (int j = 0; j < JN_FILLU; j++) {
+                const u32 i = i0 + (u32)j * JN_THREADS + tid;
+                kk[j] = i < n ? ikeys[c0 + i] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < JN_FILLU; j++) {
+                const u32 i = i0 + (u32)j * JN_THREADS + tid;
+                if (i < n) lk[i] = kk[j];
+            }
+        }
         __syncthreads();
         for (u64 q0 = qs; q0 < qe; q0 += (u64)JN_THREADS * JN_E) {
             u64 h[JN_E];
