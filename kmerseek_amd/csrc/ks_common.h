@@ -53,6 +53,11 @@ struct ks_ctx {
     u64 *h_pin = nullptr; // 64 x u64
     // matched posting pairs of recent searches (+ slack): sizes the next search's match list so the join runs once
     u64 pair_cap_hint = 0;
+    // single-launch scans (ks_prims.hip): status ring + ticket counter in device memory, never reset: every entry is
+    // tagged with the global tile number that wrote it
+    unsigned long long *scan_ring = nullptr;
+    u32 *scan_ticket = nullptr;
+    u32 scan_ticket_base = 0; // value the device counter will have when the next scan starts
     // encode LUTs (3 x 256 bytes) in device memory
     u8 *d_lut = nullptr;
 };
@@ -151,6 +156,10 @@ struct ks_kmerpos {
 // exclusive scan of n u32 values into u64 (out[n] = total is also written: out has n+1 entries)
 int ks_scan_u32_to_u64(ks_ctx *ctx, const u32 *in, u64 *out, u64 n);
 // exclusive scan u32 -> u32 in place (n < 2^32 total); optionally writes the total to d_total
+// The one-launch scans cannot report a look-back that gave up (bounded spin) by themselves: callers enqueue
+// ks_scan_status_fetch before a stream synchronisation they do anyway and call ks_scan_status_check after it.
+int ks_scan_status_fetch(ks_ctx *ctx);
+int ks_scan_status_check(ks_ctx *ctx);
 int ks_scan_u32_inplace(ks_ctx *ctx, u32 *data, u64 n, u32 *d_total);
 
 // Stable LSD radix passes over (key u64, value V) records, one 8-bit digit at each listed shift.

@@ -131,6 +131,8 @@ extern "C" void ks_ctx_destroy(ks_ctx *ctx) {
     for (auto &b : ctx->pool) (void)hipFree(b.ptr);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->scan_ring) (void)hipFree(ctx->scan_ring);
+    if (ctx->scan_ticket) (void)hipFree(ctx->scan_ticket);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

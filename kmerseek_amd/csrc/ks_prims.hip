@@ -104,6 +104,92 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_small(T *data, u64 n) {
     }
 }
 
+// One-launch exclusive scan: tiles in ticket order, the tile's offset by decoupled look-back (as the sketch kernel
+// places its CSR).  The status words live in a ring owned by the context that is never cleared: word =
+// flag (2) | tag (24) | value (38), tag = low bits of the GLOBAL tile number (ticket counter value) that wrote it, so a
+// left-over of an earlier scan never matches the tile number a reader expects (the slot was rewritten RING tiles ago
+// at the latest, and RING < 2^24).  Saves two launches (reduce + scan of the sums) per scan and the memset a fresh
+// status array would need: a step of the search runs seven scans.
+#define SCAN_RING (1u << 20)
+#define SCAN_FLAG_AGG 1ULL
+#define SCAN_FLAG_PRE 2ULL
+#define SCAN_VAL_BITS 38
+#define SCAN_SPIN_MAX (1u << 22)
+KS_DEV unsigned long long scan_word(u64 flag, u32 gtile, u64 value) {
+    return (flag << 62) | ((u64)(gtile & 0xffffffu) << SCAN_VAL_BITS) | value;
+}
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn *in, TOut *out, u64 n, TOut *total_out,
+                                                                unsigned long long *ring, u32 *ticket, u32 ticket_base,
+                                                                u32 n_tiles) {
+    __shared__ TOut smem[SCAN_THREADS / 64 + 1];
+    __shared__ u32 tile_s;
+    __shared__ unsigned long long base_s;
+    const u32 tid = threadIdx.x;
+    if (tid == 0) tile_s = atomicAdd(&ticket[0], 1u) - ticket_base;
+    __syncthreads();
+    const u32 tile = tile_s;
+    const u64 base = (u64)tile * SCAN_TILE + (u64)tid * SCAN_IPT;
+    TOut v[SCAN_IPT];
+    TOut s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) {
+        const u64 idx = base + i;
+        v[i] = idx < n ? (TOut)in[idx] : (TOut)0;
+        s += v[i];
+    }
+    TOut total;
+    const TOut ex = block_excl_scan_t<TOut>(s, smem, &total);
+    const u32 g = ticket_base + tile; // global tile number
+    if (tid == 0)
+        __hip_atomic_store(&ring[g % SCAN_RING], scan_word(tile == 0 ? SCAN_FLAG_PRE : SCAN_FLAG_AGG, g, (u64)total),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        u64 excl = 0;
+        if (tile > 0) {
+            i64 idx = (i64)tile - 1;
+            bool done = false;
+            u32 spins = 0;
+            while (!done) {
+                const i64 mine = idx - (i64)tid;
+                u64 flag = SCAN_FLAG_PRE, val = 0; // before tile 0: inclusive prefix 0
+                if (mine >= 0) {
+                    const u32 gp = ticket_base + (u32)mine;
+                    const u64 want = (u64)(gp & 0xffffffu);
+                    for (;;) {
+                        const u64 w = __hip_atomic_load(&ring[gp % SCAN_RING], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flag = w >> 62;
+                        if (flag != 0 && ((w >> SCAN_VAL_BITS) & 0xffffffu) == want) { val = w & ((1ULL << SCAN_VAL_BITS) - 1ULL); break; }
+                        flag = 0;
+                        if (++spins >= SCAN_SPIN_MAX) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                if (flag == 0) { ticket[1] = 1; flag = SCAN_FLAG_PRE; val = 0; } // gave up: the host reports it
+                const u64 is_pre = __ballot(flag == SCAN_FLAG_PRE);
+                const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
+                u64 contrib = tid <= first ? val : 0;
+                for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+                excl += contrib;
+                if (is_pre) done = true; else idx -= 64;
+            }
+            if (tid == 0)
+                __hip_atomic_store(&ring[g % SCAN_RING], scan_word(SCAN_FLAG_PRE, g, excl + (u64)total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) base_s = excl;
+    }
+    __syncthreads();
+    TOut off = (TOut)base_s + ex;
+#pragma unroll
+    for (int i = 0; i < SCAN_IPT; i++) {
+        const u64 idx = base + i;
+        if (idx < n) out[idx] = off;
+        off += v[i];
+    }
+    if (total_out && tile == n_tiles - 1 && tid == 0) *total_out = (TOut)(base_s + (u64)total);
+}
+
 template <typename TIn, typename TOut>
 static int scan_generic(ks_ctx *ctx, const TIn *in, TOut *out, u64 n, TOut *d_total) {
     if (n == 0) {
@@ -113,6 +199,22 @@ static int scan_generic(ks_ctx *ctx, const TIn *in, TOut *out, u64 n, TOut *d_to
     u64 nblocks = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nblocks == 1) {
         KS_LAUNCH(ctx, "scan_apply", (k_scan_apply<TIn, TOut>), 1, SCAN_THREADS, in, out, (const TOut *)nullptr, n, d_total);
+        return KS_OK;
+    }
+    if (nblocks <= SCAN_RING / 2 && n < (1ULL << SCAN_VAL_BITS) && !getenv("KS_DEBUG_SCAN_3PASS")) {
+        if (!ctx->scan_ring) {
+            KS_HIP(ctx, hipMalloc((void **)&ctx->scan_ring, (size_t)SCAN_RING * sizeof(unsigned long long)));
+            KS_HIP(ctx, hipMalloc((void **)&ctx->scan_ticket, 2 * sizeof(u32)));
+            KS_HIP(ctx, hipMemsetAsync(ctx->scan_ring, 0, (size_t)SCAN_RING * sizeof(unsigned long long), ctx->stream));
+            KS_HIP(ctx, hipMemsetAsync(ctx->scan_ticket, 0, 2 * sizeof(u32), ctx->stream));
+            ctx->scan_ticket_base = 0;
+        }
+        ks_timer_begin(ctx, "scan_lookback");
+        hipLaunchKernelGGL((k_scan_lookback<TIn, TOut>), dim3((u32)nblocks), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, d_total,
+                           ctx->scan_ring, ctx->scan_ticket, ctx->scan_ticket_base, (u32)nblocks);
+        ks_timer_end(ctx);
+        if (hipGetLastError() != hipSuccess) return ks_fail(ctx, KS_ERR_HIP, "scan launch failed");
+        ctx->scan_ticket_base += (u32)nblocks;
         return KS_OK;
     }
     TOut *sums = nullptr;
@@ -134,6 +236,18 @@ static int scan_generic(ks_ctx *ctx, const TIn *in, TOut *out, u64 n, TOut *d_to
     }
     ks_pool_free(ctx, sums); // stream-ordered reuse: later kernels on the same stream run after this one
     return st;
+}
+
+int ks_scan_status_fetch(ks_ctx *ctx) {
+    if (!ctx->scan_ticket) return KS_OK;
+    KS_HIP(ctx, hipMemcpyAsync(ctx->h_pin + 40, ctx->scan_ticket + 1, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    return KS_OK;
+}
+int ks_scan_status_check(ks_ctx *ctx) {
+    if (!ctx->scan_ticket || *(u32 *)(ctx->h_pin + 40) == 0) return KS_OK;
+    *(u32 *)(ctx->h_pin + 40) = 0;
+    (void)hipMemsetAsync(ctx->scan_ticket + 1, 0, sizeof(u32), ctx->stream);
+    return ks_fail(ctx, KS_ERR_HIP, "scan: look-back gave up waiting for a predecessor tile");
 }
 
 int ks_scan_u32_to_u64(ks_ctx *ctx, const u32 *in, u64 *out, u64 n) {

@@ -92,7 +92,9 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
     } else {
         ix->d_keys = k0; k0 = nullptr;
     }
+    IX_CHECK(ks_scan_status_fetch(ctx));
     IX_HIP(hipStreamSynchronize(ctx->stream));
+    IX_CHECK(ks_scan_status_check(ctx));
 done:
     ks_pool_free(ctx, k0); ks_pool_free(ctx, k1); ks_pool_free(ctx, v0); ks_pool_free(ctx, v1); ks_pool_free(ctx, d_max);
     if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_index_free(ix); return st; }
@@ -506,7 +508,9 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
                            n_pairs, H->d_qid, H->d_tid, H->d_isect, (unsigned long long *)H->d_nw, tbits, abits);
         ks_timer_end(ctx);
         SE_HIP(hipGetLastError());
+        SE_CHECK(ks_scan_status_fetch(ctx));
         SE_HIP(hipStreamSynchronize(ctx->stream));
+        SE_CHECK(ks_scan_status_check(ctx));
     }
 done:
     ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
@@ -584,7 +588,9 @@ int ks_union_impl(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out) {
         UN_HIP(hipGetLastError());
         ctx->h_pin[0] = 0; ctx->h_pin[1] = n_rows;
         UN_HIP(hipMemcpyAsync(U->d_offsets, ctx->h_pin, 2 * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        UN_CHECK(ks_scan_status_fetch(ctx));
         UN_HIP(hipStreamSynchronize(ctx->stream));
+        UN_CHECK(ks_scan_status_check(ctx));
     }
 done:
     ks_pool_free(ctx, k0); ks_pool_free(ctx, k1); ks_pool_free(ctx, v0); ks_pool_free(ctx, v1);
