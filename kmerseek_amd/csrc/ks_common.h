@@ -183,6 +183,9 @@ int ks_radix_sort_keys(ks_ctx *ctx, int tag, const u64 *keys_in, u64 *ka, u64 *k
                        u64 **keys_out);
 int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, const ks_rs_segments *seg, int shift,
                           u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status);
+// index build in three passes (two partition passes + in-LDS bucket sort); *overflowed = 1: use the LSD sort instead
+int ks_index_sort_partitioned(ks_ctx *ctx, const u64 *keys_in, const u64 *vals_in, u64 n, u64 max_hash, u64 *okeys, u32 *otids,
+                              u32 *oabunds, u32 *d_max_abund, int *overflowed);
 int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_in, u64 *ka, u64 *va, u64 *kb, u64 *vb,
                       u64 n, const int *shifts, int n_shifts, u64 **keys_out, u64 **vals_out);
 

@@ -511,6 +511,264 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
         if (gdst[i] != ~0ULL) vout[gdst[i]] = vstage[(u32)i * RS_THREADS + tid];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Index build: (hash, abund << 32 | tid) postings -> dense arrays sorted by (hash, tid) in THREE passes over the data
+// instead of the eight of a 64-bit LSD sort: two fixed-capacity partition passes on the bits of a SORT prefix
+// (floor(hash * 2^S / (max_hash + 1)), S <= 18, ~1100 postings per sort bucket) and one pass that sorts every
+// bucket inside LDS.  Murmur output is uniform, so fixed capacities hold; a pass that would overflow raises a flag
+// and the host falls back to the LSD sort (skewed inputs: thousands of copies of one protein).
+// ---------------------------------------------------------------------------------------------
+// One partition pass, up to 512 digits: record -> bucket (region * rmul + digit), digit = (prefix >> shift) & dmask,
+// region = the input segment of the tile (0 for a dense input).  Ranks inside (tile, digit) are LDS atomic returns
+// (order inside a bucket does not matter to the bucket sort); one global atomic per (tile, digit) reserves the slice.
+__global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_part_scatter64(const u64 *kin, const u64 *vin, u64 *kout, u64 *vout, u64 n,
+                                                                        const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg,
+                                                                        int shift, u32 dmask, u32 pfxK, u32 rmul, u32 *bcur,
+                                                                        u64 bcap, u32 *overflow) {
+    __shared__ u32 cnt[512];
+    __shared__ u32 dstart[512];
+    __shared__ u32 gbase[512];
+    __shared__ u32 scan_smem[RS_WAVES + 1];
+    __shared__ __attribute__((aligned(16))) u64 stage[RS_TILE];
+    static_assert(RS_THREADS == 512, "one thread per digit");
+    const u32 tid = threadIdx.x;
+    u64 tile_base;
+    u32 nvalid;
+    rs_tile_geom(n, seg_len, seg_cap, tiles_per_seg, tile_base, nvalid);
+    if (nvalid == 0) return;
+    const u32 region = seg_len ? blockIdx.x / tiles_per_seg : 0u;
+    cnt[tid] = 0;
+    u64 key[RS_IPT];
+    u64 val[RS_IPT];
+    u32 rank[RS_IPT];
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++) {
+        const u32 li = (u32)r * RS_THREADS + tid;
+        const bool valid = li < nvalid;
+        key[r] = valid ? kin[tile_base + li] : 0ULL;
+        val[r] = valid ? vin[tile_base + li] : 0ULL;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++) {
+        const u32 li = (u32)r * RS_THREADS + tid;
+        rank[r] = 0xffffffffu;
+        if (li < nvalid) {
+            const u32 d = (ks_join_prefix(key[r], pfxK) >> shift) & dmask;
+            rank[r] = (d << 16) | atomicAdd(&cnt[d], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        const u32 c = cnt[tid];
+        u32 total;
+        const u32 ds = ks_block_excl_scan(c, scan_smem, &total);
+        dstart[tid] = ds;
+        u32 base = 0;
+        if (c) {
+            base = atomicAdd(&bcur[region * rmul + tid], c);
+            if ((u64)base + c > bcap) atomicOr(overflow, 1u);
+        }
+        gbase[tid] = base;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++)
+        if (rank[r] != 0xffffffffu) {
+            rank[r] = dstart[rank[r] >> 16] + (rank[r] & 0xffffu);
+            stage[rank[r]] = key[r];
+        }
+    __syncthreads();
+    u64 gdst[RS_IPT];
+#pragma unroll
+    for (int i = 0; i < RS_IPT; i++) {
+        const u32 p = (u32)i * RS_THREADS + tid;
+        gdst[i] = ~0ULL;
+        if (p < nvalid) {
+            const u64 k = stage[p];
+            const u32 d = (ks_join_prefix(k, pfxK) >> shift) & dmask;
+            const u64 slot = (u64)gbase[d] + (p - dstart[d]);
+            if (slot < bcap) {
+                gdst[i] = (u64)(region * rmul + d) * bcap + slot;
+                kout[gdst[i]] = k;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++)
+        if (rank[r] != 0xffffffffu) stage[rank[r]] = val[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RS_IPT; i++)
+        if (gdst[i] != ~0ULL) vout[gdst[i]] = stage[(u32)i * RS_THREADS + tid];
+}
+
+// Sort one bucket (<= BS_CAP postings) inside LDS and write it to its place in the dense index.  Hashes are uniform
+// inside a bucket too, so posting (h, tid) goes to sub-bucket floor(frac(h) * n) (frac = position of h inside the
+// bucket's hash range, 32 bits; monotone in h) — about one posting per sub-bucket — and its final rank is the
+// sub-bucket's start plus the number of smaller (hash, tid, arrival) triples in it.  O(n) LDS work, no comparison sort.
+#define BS_THREADS 256
+#define BS_E 8
+#define BS_CAP (BS_THREADS * BS_E)
+__global__ __launch_bounds__(BS_THREADS) void k_bucket_sort(const u64 *bkeys, const u64 *bvals, const u32 *bcount, u64 bcap,
+                                                            const u64 *dense_start, u32 pfxK, u64 *okeys, u32 *otids,
+                                                            u32 *oabunds, u32 *max_abund) {
+    __shared__ u64 tk[BS_CAP];
+    __shared__ u32 tt[BS_CAP];
+    __shared__ u32 cnt[BS_CAP + 1];
+    __shared__ u32 scan_smem[BS_THREADS / 64 + 1];
+    const u32 tid = threadIdx.x, b = blockIdx.x;
+    const u32 n = bcount[b];
+    if (n == 0) return;
+    const u64 src = (u64)b * bcap, dst = dense_start[b];
+    u64 key[BS_E], val[BS_E];
+    u32 so[BS_E]; // sub-bucket << 12 | arrival slot (n <= 2048: 11 bits each)
+#pragma unroll
+    for (int e = 0; e < BS_E; e++) cnt[(u32)e * BS_THREADS + tid] = 0;
+    if (tid == 0) cnt[BS_CAP] = 0;
+#pragma unroll
+    for (int e = 0; e < BS_E; e++) {
+        const u32 i = (u32)e * BS_THREADS + tid;
+        key[e] = i < n ? bkeys[src + i] : 0ULL;
+        val[e] = i < n ? bvals[src + i] : 0ULL;
+    }
+    __syncthreads();
+    u32 amax = 0;
+#pragma unroll
+    for (int e = 0; e < BS_E; e++) {
+        const u32 i = (u32)e * BS_THREADS + tid;
+        so[e] = 0xffffffffu;
+        if (i < n) {
+            const u32 frac = (u32)((u64)(u32)(key[e] >> 32) * pfxK); // low word of the product whose high word is the bucket
+            const u32 sb = __umulhi(frac, n);
+            so[e] = (sb << 12) | atomicAdd(&cnt[sb], 1u);
+            const u32 a = (u32)(val[e] >> 32);
+            amax = a > amax ? a : amax;
+        }
+    }
+    __syncthreads();
+    { // counts -> starts (8 consecutive sub-buckets per thread)
+        u32 c[BS_E], s = 0;
+#pragma unroll
+        for (int e = 0; e < BS_E; e++) { c[e] = cnt[tid * BS_E + e]; s += c[e]; }
+        u32 total;
+        u32 ex = ks_block_excl_scan(s, scan_smem, &total);
+#pragma unroll
+        for (int e = 0; e < BS_E; e++) { cnt[tid * BS_E + e] = ex; ex += c[e]; }
+        if (tid == BS_THREADS - 1) cnt[BS_CAP] = total;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < BS_E; e++)
+        if (so[e] != 0xffffffffu) {
+            const u32 p = cnt[so[e] >> 12] + (so[e] & 0xfffu);
+            tk[p] = key[e];
+            tt[p] = (u32)val[e];
+        }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < BS_E; e++)
+        if (so[e] != 0xffffffffu) {
+            const u32 sb = so[e] >> 12, o = so[e] & 0xfffu;
+            const u32 s0 = cnt[sb], c = cnt[sb + 1] - s0; // (sub-buckets >= n are empty: their start is the total)
+            const u32 t = (u32)val[e];
+            u32 less = 0;
+            for (u32 j = 0; j < c; j++) {
+                const u64 kj = tk[s0 + j];
+                const u32 tj = tt[s0 + j];
+                less += (kj < key[e]) || (kj == key[e] && (tj < t || (tj == t && j < o)));
+            }
+            const u64 p = dst + s0 + less;
+            okeys[p] = key[e];
+            otids[p] = t;
+            oabunds[p] = (u32)(val[e] >> 32);
+        }
+    for (int d = 32; d > 0; d >>= 1) {
+        const u32 o = __shfl_down(amax, d, 64);
+        amax = o > amax ? o : amax;
+    }
+    if ((tid & 63) == 0 && amax > *max_abund) atomicMax(max_abund, amax);
+}
+
+// returns KS_OK with *overflowed = 1 when a fixed capacity did not hold (nothing usable was written)
+int ks_index_sort_partitioned(ks_ctx *ctx, const u64 *keys_in, const u64 *vals_in, u64 n, u64 max_hash, u64 *okeys, u32 *otids,
+                              u32 *oabunds, u32 *d_max_abund, int *overflowed) {
+    *overflowed = 0;
+    // sort-prefix bits: ~1100 postings per bucket, at most 18 (two 9-bit partition passes)
+    int S = 0;
+    while (S < 18 && (n >> S) > 1100) S++;
+    const int lo = S < 9 ? S : 9, hi = S - lo;
+    const u32 n_buckets = 1u << S;
+    const u64 per = n >> S;
+    u64 bcap = per + per / 4 + 64;
+    { u64 r = 8; while (r * r < per * 64) r++; bcap += r; } // + 8 sigma of a Poisson bucket
+    if (bcap > BS_CAP) bcap = BS_CAP;
+    const u32 pfxK = ks_join_prefix_mul(S, max_hash); // hi32(hash) * K: high word = sort bucket, low word = place inside it
+    u64 *ak = nullptr, *av = nullptr, *bk = nullptr, *bv = nullptr, *dpos = nullptr;
+    u32 *acur = nullptr, *bcur = nullptr, *oflow = nullptr;
+    int st = KS_OK;
+    const u32 nA = 1u << hi;
+    u64 capA = 0;
+#define PS_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
+    PS_CHECK(ks_alloc(ctx, &bcur, (size_t)n_buckets + 1));
+    PS_CHECK(ks_alloc(ctx, &oflow, 1));
+    PS_CHECK(ks_alloc(ctx, &dpos, (size_t)n_buckets + 1));
+    (void)hipMemsetAsync(bcur, 0, ((size_t)n_buckets + 1) * sizeof(u32), ctx->stream);
+    (void)hipMemsetAsync(oflow, 0, sizeof(u32), ctx->stream);
+    if (S > 0) {
+        PS_CHECK(ks_alloc(ctx, &bk, (size_t)n_buckets * bcap));
+        PS_CHECK(ks_alloc(ctx, &bv, (size_t)n_buckets * bcap));
+    }
+    if (hi > 0) { // pass A: dense input -> 2^hi regions on the high bits of the sort prefix
+        const u64 perA = n >> hi;
+        capA = perA + perA / 8 + 8192;
+        capA = (capA + RS_TILE - 1) / RS_TILE * RS_TILE;
+        PS_CHECK(ks_alloc(ctx, &ak, (size_t)nA * capA));
+        PS_CHECK(ks_alloc(ctx, &av, (size_t)nA * capA));
+        PS_CHECK(ks_alloc(ctx, &acur, (size_t)nA));
+        (void)hipMemsetAsync(acur, 0, (size_t)nA * sizeof(u32), ctx->stream);
+        const u32 nblocks = (u32)((n + RS_TILE - 1) / RS_TILE);
+        ks_timer_begin(ctx, "index_part_a");
+        hipLaunchKernelGGL(k_part_scatter64, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in, ak, av, n,
+                           (const u32 *)nullptr, (u64)0, 0u, lo, nA - 1, pfxK, 0u, acur, capA, oflow);
+        ks_timer_end(ctx);
+        // pass B: regions -> sort buckets (region << lo | low digit)
+        const u32 tps = (u32)(capA / RS_TILE);
+        ks_timer_begin(ctx, "index_part_b");
+        hipLaunchKernelGGL(k_part_scatter64, dim3(nA * tps), dim3(RS_THREADS), 0, ctx->stream, (const u64 *)ak, (const u64 *)av, bk, bv,
+                           (u64)0, (const u32 *)acur, capA, tps, 0, (1u << lo) - 1, pfxK, 1u << lo, bcur, bcap, oflow);
+        ks_timer_end(ctx);
+    } else if (S > 0) { // one pass is enough
+        const u32 nblocks = (u32)((n + RS_TILE - 1) / RS_TILE);
+        ks_timer_begin(ctx, "index_part_b");
+        hipLaunchKernelGGL(k_part_scatter64, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in, bk, bv, n,
+                           (const u32 *)nullptr, (u64)0, 0u, 0, n_buckets - 1, pfxK, 0u, bcur, bcap, oflow);
+        ks_timer_end(ctx);
+    } else { // a single bucket: the input is the bucket
+        if (n > BS_CAP) { *overflowed = 1; goto done; }
+        const u32 cnt1 = (u32)n;
+        (void)hipMemcpyAsync(bcur, &cnt1, sizeof(u32), hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (hipGetLastError() != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "index partition launch failed"); goto done; }
+    // overflow flags decide before anything is sorted
+    if (hipMemcpyAsync(ctx->h_pin + 41, oflow, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "index partition status read failed"); goto done; }
+    if (*(u32 *)(ctx->h_pin + 41) != 0) { *overflowed = 1; goto done; }
+    PS_CHECK(ks_scan_u32_to_u64(ctx, bcur, dpos, n_buckets));
+    ks_timer_begin(ctx, "index_bucket_sort");
+    hipLaunchKernelGGL(k_bucket_sort, dim3(n_buckets), dim3(BS_THREADS), 0, ctx->stream, S ? (const u64 *)bk : keys_in,
+                       S ? (const u64 *)bv : vals_in, (const u32 *)bcur, S ? bcap : (u64)0, (const u64 *)dpos, pfxK, okeys, otids, oabunds,
+                       d_max_abund);
+    ks_timer_end(ctx);
+    if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "index bucket sort launch failed");
+done:
+    ks_pool_free(ctx, ak); ks_pool_free(ctx, av); ks_pool_free(ctx, bk); ks_pool_free(ctx, bv); ks_pool_free(ctx, dpos);
+    ks_pool_free(ctx, acur); ks_pool_free(ctx, bcur); ks_pool_free(ctx, oflow);
+    return st;
+#undef PS_CHECK
+}
+
 static const char *const rs_tag_names[3] = {"index", "qpart", "pairs"};
 
 template <typename V, int TAG>

@@ -61,35 +61,48 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
     int st = KS_OK;
 #define IX_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
 #define IX_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
-    IX_CHECK(ks_alloc(ctx, &k0, (size_t)n));
-    IX_CHECK(ks_alloc(ctx, &k1, (size_t)n));
     IX_CHECK(ks_alloc(ctx, &v0, (size_t)n));
-    IX_CHECK(ks_alloc(ctx, &v1, (size_t)n));
     IX_CHECK(ks_alloc(ctx, &ix->d_tids, (size_t)n));
     IX_CHECK(ks_alloc(ctx, &ix->d_abunds, (size_t)n));
+    IX_CHECK(ks_alloc(ctx, &d_max, 1));
+    IX_HIP(hipMemsetAsync(d_max, 0, sizeof(u32), ctx->stream));
     if (n > 0) {
-        // values = (abund << 32 | tid) in v0; keys are read straight from the sketches on the first pass
+        // values = (abund << 32 | tid); keys are read straight from the sketches
         ks_timer_begin(ctx, "fill_index_vals");
         hipLaunchKernelGGL(k_fill_index_vals, dim3((t->n_seqs + 3) / 4), dim3(256), 0, ctx->stream, (const u64 *)t->d_offsets,
                            (const u32 *)t->d_abunds, t->n_seqs, v0);
         ks_timer_end(ctx);
         IX_HIP(hipGetLastError());
-        const int shifts[8] = {0, 8, 16, 24, 32, 40, 48, 56};
-        u64 *ks = nullptr, *vs = nullptr;
-        // v0 holds the input values, so the first pass must land in (k1, v1): pass it as the "a" pair
-        IX_CHECK(ks_radix_sort_u64(ctx, KS_SORT_INDEX, t->d_hashes, v0, k1, v1, k0, v0, n, shifts, 8, &ks, &vs));
-        IX_CHECK(ks_alloc(ctx, &d_max, 1));
-        IX_HIP(hipMemsetAsync(d_max, 0, sizeof(u32), ctx->stream));
-        ks_timer_begin(ctx, "split_vals");
-        hipLaunchKernelGGL(k_split_vals, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u64 *)vs, n, ix->d_tids, ix->d_abunds, d_max);
-        ks_timer_end(ctx);
-        IX_HIP(hipGetLastError());
+        // three passes: partition on the sort prefix twice, sort the buckets in LDS (ks_prims.hip)
+        int overflowed = 0;
+        IX_CHECK(ks_alloc(ctx, &k0, (size_t)n));
+        if (!getenv("KS_DEBUG_INDEX_LSD"))
+            IX_CHECK(ks_index_sort_partitioned(ctx, t->d_hashes, v0, n, ks_max_hash(t->params.scaled), k0, ix->d_tids, ix->d_abunds, d_max,
+                                               &overflowed));
+        else
+            overflowed = 1;
+        if (!overflowed) {
+            ix->d_keys = k0; k0 = nullptr;
+        } else {
+            // skewed hashes (a fixed capacity did not hold): the always-correct 8-pass LSD sort
+            IX_CHECK(ks_alloc(ctx, &k1, (size_t)n));
+            IX_CHECK(ks_alloc(ctx, &v1, (size_t)n));
+            const int shifts[8] = {0, 8, 16, 24, 32, 40, 48, 56};
+            u64 *ks = nullptr, *vs = nullptr;
+            // v0 holds the input values, so the first pass must land in (k1, v1): pass it as the "a" pair
+            IX_CHECK(ks_radix_sort_u64(ctx, KS_SORT_INDEX, t->d_hashes, v0, k1, v1, k0, v0, n, shifts, 8, &ks, &vs));
+            IX_HIP(hipMemsetAsync(d_max, 0, sizeof(u32), ctx->stream));
+            ks_timer_begin(ctx, "split_vals");
+            hipLaunchKernelGGL(k_split_vals, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u64 *)vs, n, ix->d_tids, ix->d_abunds, d_max);
+            ks_timer_end(ctx);
+            IX_HIP(hipGetLastError());
+            if (ks == k0) { ix->d_keys = k0; k0 = nullptr; } else { ix->d_keys = k1; k1 = nullptr; }
+        }
         IX_HIP(hipMemcpyAsync(ctx->h_pin, d_max, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
         IX_HIP(hipStreamSynchronize(ctx->stream));
         ix->max_abund = *(u32 *)ctx->h_pin;
-        // keep the sorted key buffer, release the other
-        if (ks == k0) { ix->d_keys = k0; k0 = nullptr; } else { ix->d_keys = k1; k1 = nullptr; }
     } else {
+        IX_CHECK(ks_alloc(ctx, &k0, 1));
         ix->d_keys = k0; k0 = nullptr;
     }
     IX_CHECK(ks_scan_status_fetch(ctx));

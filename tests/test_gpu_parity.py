@@ -410,3 +410,50 @@ def test_unpacked_match_records_equal_packed(ctx, monkeypatch):
     assert len(a[0]) > 0
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("nt,k,scaled,mol", [(3, 5, 1, "protein"), (40, 10, 1, "protein"), (2500, 7, 1, "hp"), (9000, 10, 1, "protein"),
+                                              (30000, 16, 5, "dayhoff")])
+def test_index_build_paths_agree(ctx, monkeypatch, nt, k, scaled, mol):
+    """The index is built in three passes (two partition passes on a sort prefix + an in-LDS bucket sort: no bucket,
+    one partition pass or two, depending on the size) with the 8-pass LSD sort as the fallback for skewed hashes:
+    the same hits either way, and the same as the oracle."""
+    t_res, t_off = synth.proteome(nt, stream=300 + nt)
+    q_res, q_off = synth.queries(max(nt // 2, 3), t_res, t_off, stream=301 + nt)
+    T = ctx.sketch_batch(t_res, t_off, k, scaled, mol)
+    Q = ctx.sketch_batch(q_res, q_off, k, scaled, mol)
+    a = ctx.search(ctx.index_build(T), Q).to_host()
+    monkeypatch.setenv("KS_DEBUG_INDEX_LSD", "1")
+    b = ctx.search(ctx.index_build(T), Q).to_host()
+    monkeypatch.delenv("KS_DEBUG_INDEX_LSD")
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    if nt <= 2500:
+        to, tm, ta = T.to_host()
+        qo, qm, _ = Q.to_host()
+        want = oracle.manysearch(qo, qm, to, tm, ta, n_threads=8)
+        for x, y in zip(a, want):
+            assert np.array_equal(x, y)
+
+
+def test_index_build_falls_back_on_duplicated_targets(ctx, monkeypatch):
+    """4000 copies of one protein: every hash of the index occurs 4000 times, so the sort buckets overflow their fixed
+    capacity and the build must take the LSD path — same hits as forcing that path, and every query finds every copy."""
+    rng = np.random.default_rng(8)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    prot = bytes(rng.choice(aa, size=300).tolist())
+    other = [bytes(rng.choice(aa, size=int(n)).tolist()) for n in rng.integers(50, 400, 50)]
+    t_res, t_off = ks.pack([prot] * 4000 + other)
+    q_res, q_off = ks.pack([prot[:150], other[3], prot])
+    T = ctx.sketch_batch(t_res, t_off, 10, 1, "protein")
+    Q = ctx.sketch_batch(q_res, q_off, 10, 1, "protein")
+    a = ctx.search(ctx.index_build(T), Q).to_host()
+    monkeypatch.setenv("KS_DEBUG_INDEX_LSD", "1")
+    b = ctx.search(ctx.index_build(T), Q).to_host()
+    monkeypatch.delenv("KS_DEBUG_INDEX_LSD")
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    qid, tid, isect, nw = a
+    assert int((qid == 0).sum()) == 4000 and int((qid == 2).sum()) == 4000
+    assert set(isect[qid == 2].tolist()) == {291} and set(isect[qid == 0].tolist()) == {141}
+    assert tid[qid == 1].tolist() == [4003] and isect[qid == 1].tolist() == [len(other[3]) - 9]
