@@ -134,6 +134,8 @@ struct ks_index {
     u32 *d_tids;   // target id per posting
     u32 *d_abunds; // target abundance per posting
     u32 max_abund; // largest of them: how many low bits of a packed match record the abundance needs
+    u64 *d_dir;    // join-bucket directory: d_dir[b] = first posting whose join prefix is >= b (2^pbits + 1 entries)
+    int pbits;     // join prefix bits, a function of n_postings alone (ks_join_pbits)
 };
 
 struct ks_hits {

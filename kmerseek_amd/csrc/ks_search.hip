@@ -46,6 +46,9 @@ __global__ __launch_bounds__(256) void k_split_vals(const u64 *vals, u64 n, u32 
     if ((threadIdx.x & 63) == 0 && a > *max_abund) atomicMax(max_abund, a); // (plain read first: almost every wave's maximum is already covered)
 }
 
+int ks_join_pbits(u64 n_postings);
+__global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int pbits, u32 pfxK, u64 *dir);
+
 int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
     if (!t || !out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     KS_HIP(ctx, hipSetDevice(ctx->device));
@@ -104,6 +107,17 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
     } else {
         IX_CHECK(ks_alloc(ctx, &k0, 1));
         ix->d_keys = k0; k0 = nullptr;
+    }
+    {
+        // the join-bucket directory belongs to the index (its prefix width depends on the posting count alone)
+        ix->pbits = ks_join_pbits(n);
+        const u32 nb = 1u << ix->pbits;
+        IX_CHECK(ks_alloc(ctx, &ix->d_dir, (size_t)nb + 1));
+        ks_timer_begin(ctx, "bucket_dir");
+        hipLaunchKernelGGL(k_bucket_dir, dim3((nb + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys, n, ix->pbits,
+                           ks_join_prefix_mul(ix->pbits, ks_max_hash(t->params.scaled)), ix->d_dir);
+        ks_timer_end(ctx);
+        IX_HIP(hipGetLastError());
     }
     IX_CHECK(ks_scan_status_fetch(ctx));
     IX_HIP(hipStreamSynchronize(ctx->stream));
@@ -352,7 +366,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
     memset(H, 0, sizeof *H);
     H->ctx = ctx;
     const u64 n_q = q->n_hashes, n_t = ix->n_postings;
-    u64 *qk0 = nullptr, *qk1 = nullptr, *pk0 = nullptr, *pk1 = nullptr, *row_start = nullptr, *dir_q = nullptr, *dir_t = nullptr;
+    u64 *qk0 = nullptr, *qk1 = nullptr, *pk0 = nullptr, *pk1 = nullptr, *row_start = nullptr, *dir_q = nullptr;
     u32 *qv0 = nullptr, *qv1 = nullptr, *pv0 = nullptr, *pv1 = nullptr, *heads = nullptr, *d_nrows = nullptr, *bcur = nullptr;
     unsigned long long *cursor = nullptr;
     int st = KS_OK;
@@ -377,12 +391,8 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
         if (!packed) abits = 0;
         const u32 pfxK = ks_join_prefix_mul(pbits, ks_max_hash(ix->params.scaled));
         SE_CHECK(ks_alloc(ctx, &dir_q, (size_t)2 * n_buckets + 2));
-        SE_CHECK(ks_alloc(ctx, &dir_t, (size_t)n_buckets + 1));
+        const u64 *dir_t = ix->d_dir; // built with the index
         SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, 2)); // [0] matches appended, [1] a query bucket overflowed
-        ks_timer_begin(ctx, "bucket_dir");
-        hipLaunchKernelGGL(k_bucket_dir, dim3((n_buckets + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys, n_t, pbits, pfxK, dir_t);
-        ks_timer_end(ctx);
-        SE_HIP(hipGetLastError());
         const bool pre = q->part_keys && q->part_pbits == pbits && q->part_K == pfxK && pbits > 0;
         u64 cap = n_q < (1u << 20) ? (1u << 20) : n_q;
         if (ctx->pair_cap_hint > cap) cap = ctx->pair_cap_hint; // a workload that matched heavily last time will again
@@ -453,7 +463,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
                 ks_timer_begin(ctx, "join_buckets");
                 hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
                                    (const u32 *)qv, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds,
-                                   q_lo, q_hi, (const u64 *)dir_t, pk0, pv0, cap, cursor, tbits, abits);
+                                   q_lo, q_hi, dir_t, pk0, pv0, cap, cursor, tbits, abits);
                 ks_timer_end(ctx);
                 SE_HIP(hipGetLastError());
                 SE_HIP(hipMemcpyAsync(ctx->h_pin, cursor, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
@@ -529,7 +539,7 @@ done:
     ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
     ks_pool_free(ctx, pk0); ks_pool_free(ctx, pk1); ks_pool_free(ctx, pv0); ks_pool_free(ctx, pv1);
     ks_pool_free(ctx, heads); ks_pool_free(ctx, d_nrows); ks_pool_free(ctx, row_start); ks_pool_free(ctx, cursor);
-    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, dir_t); ks_pool_free(ctx, bcur);
+    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, bcur);
     if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_hits_free(H); return st; }
     *out = H;
     return KS_OK;
