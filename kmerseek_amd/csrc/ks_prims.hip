@@ -420,7 +420,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
 }
 
 // The last partition pass of a search: segmented postings (region r = low digit of the join prefix) -> 2^pbits
-// fixed-capacity buckets (bucket (d << 8 | r) at bucket * bcap, d = high digit).  Each tile reserves its slice of a
+// fixed-capacity buckets (bucket (d << 8 | r) in storage slot KS_BSLOT(d, r) * bcap, d = high digit).  Each tile reserves its slice of a
 // bucket with one global atomic per digit, so there is no histogram pass and no scan; order inside a bucket is
 // irrelevant to the join, so the rank of a record inside its (tile, digit) group is just the return value of one LDS
 // atomic — no ballot matching, no per-wave counters.  A bucket that would overflow raises status[1] and the host
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
 __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout,
                                                                         int shift, const u32 *seg_len, u64 seg_cap,
                                                                         u32 tiles_per_seg, u32 *bcur, u32 bcap,
-                                                                        unsigned long long *status, u32 pfxK) {
+                                                                        unsigned long long *status, u32 pfxK, u32 n_hi) {
     __shared__ u32 cnt[256];
     __shared__ u32 dstart[256];
     __shared__ u32 gbase[256];
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
             dstart[tid] = ds;
             u32 base = 0;
             if (c) {
-                base = atomicAdd(&bcur[(tid << 8) | region], c);
+                base = atomicAdd(&bcur[KS_BSLOT(tid, region, n_hi)], c);
                 if (base + c > bcap) atomicOr(&status[1], 1ULL);
             }
             gbase[tid] = base;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
             const u32 d = ks_rs_digit(k, shift, pfxK);
             const u32 slot = gbase[d] + (p - dstart[d]);
             if (slot < bcap) {
-                gdst[i] = (u64)((d << 8) | region) * bcap + slot;
+                gdst[i] = (u64)KS_BSLOT(d, region, n_hi) * bcap + slot;
                 kout[gdst[i]] = k;
             }
         }
@@ -840,12 +840,12 @@ int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_
 
 // One pass, no histogram: segmented postings (regions by the low digit) -> 2^pbits fixed-capacity buckets.
 int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, const ks_rs_segments *seg, int shift,
-                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status) {
+                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status, u32 n_hi) {
     const u32 tiles_per_seg = (u32)((seg->cap + RS_TILE - 1) / RS_TILE);
     const u32 nblocks = seg->regions * tiles_per_seg;
     ks_timer_begin(ctx, "bucket_scatter");
     hipLaunchKernelGGL(k_bucket_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in, bkeys, bvals, shift,
-                       seg->len, seg->cap, tiles_per_seg, bcur, bcap, status, pfxK);
+                       seg->len, seg->cap, tiles_per_seg, bcur, bcap, status, pfxK, n_hi);
     ks_timer_end(ctx);
     KS_HIP(ctx, hipGetLastError());
     return KS_OK;

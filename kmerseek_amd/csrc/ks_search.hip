@@ -181,11 +181,13 @@ u32 ks_join_prefix_mul(int pbits, u64 max_hash) {
 }
 
 // query-side bucket bounds when the sketch kernel's regions ARE the buckets (pbits <= 8): no partition pass at all
-__global__ __launch_bounds__(256) void k_region_dir(const u32 *len, u64 cap, u32 n_regions, u64 *lo, u64 *hi) {
+__global__ __launch_bounds__(256) void k_region_dir(const u32 *len, u64 cap, u32 n_regions, u64 *lo, u64 *hi, u32 n_hi) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_regions) return;
-    lo[b] = (u64)b * cap;
-    hi[b] = (u64)b * cap + len[b];
+    // n_hi != 0: b is a join prefix (high digit << 8 | region) and its postings sit in storage slot KS_BSLOT
+    const u32 slot = n_hi ? KS_BSLOT(b >> 8, b & 255u, n_hi) : b;
+    lo[b] = (u64)slot * cap;
+    hi[b] = (u64)slot * cap + len[slot];
 }
 
 // dir[b] = first posting whose join prefix is >= b, for b in [0, 2^pbits]; keys are ordered on the prefix
@@ -412,10 +414,10 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
                 SE_CHECK(ks_alloc(ctx, &bcur, (size_t)n_buckets));
                 SE_HIP(hipMemsetAsync(bcur, 0, (size_t)n_buckets * sizeof(u32), ctx->stream));
                 ks_rs_segments seg{q->part_len, q->part_cap, q->part_regions};
-                SE_CHECK(ks_bucket_scatter_u32(ctx, q->part_keys, q->part_vals, &seg, 8, pfxK, qk0, qv0, bcur, bcap, cursor));
+                SE_CHECK(ks_bucket_scatter_u32(ctx, q->part_keys, q->part_vals, &seg, 8, pfxK, qk0, qv0, bcur, bcap, cursor, n_buckets >> 8));
                 ks_timer_begin(ctx, "bucket_dir");
                 hipLaunchKernelGGL(k_region_dir, dim3((n_buckets + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)bcur, (u64)bcap,
-                                   n_buckets, dir_q, dir_q + n_buckets);
+                                   n_buckets, dir_q, dir_q + n_buckets, n_buckets >> 8);
                 ks_timer_end(ctx);
                 qk = qk0; qv = qv0; q_lo = dir_q; q_hi = dir_q + n_buckets;
             } else if (pre && pbits <= 8) {
@@ -423,7 +425,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
                 qk = q->part_keys; qv = q->part_vals;
                 ks_timer_begin(ctx, "bucket_dir");
                 hipLaunchKernelGGL(k_region_dir, dim3((n_buckets + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)q->part_len,
-                                   q->part_cap, n_buckets, dir_q, dir_q + n_buckets);
+                                   q->part_cap, n_buckets, dir_q, dir_q + n_buckets, 0u);
                 ks_timer_end(ctx);
                 q_lo = dir_q; q_hi = dir_q + n_buckets;
             } else {
