@@ -1156,6 +1156,9 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                 const double cost = (double)(n_res / sk_r_cand_host[c] + 1) + 1.75 * (double)ctx->h_pin[4 + c];
                 if (c == 0 || cost < best) { best = cost; tile_R = sk_r_cand_host[c]; n_med = ctx->h_pin[4 + c]; }
             }
+            if (const char *force = getenv("KS_DEBUG_TILE_R")) // tuning aid: index into sk_r_cand (counted strides only)
+                for (int c = 0; c < SK_NR - 2; c++)
+                    if (atoi(force) == (int)sk_r_cand_host[c]) { tile_R = sk_r_cand_host[c]; n_med = ctx->h_pin[4 + c]; }
         }
     }
     {
