@@ -413,7 +413,7 @@ def test_unpacked_match_records_equal_packed(ctx, monkeypatch):
 
 
 @pytest.mark.parametrize("nt,k,scaled,mol", [(3, 5, 1, "protein"), (40, 10, 1, "protein"), (2500, 7, 1, "hp"), (9000, 10, 1, "protein"),
-                                              (30000, 16, 5, "dayhoff")])
+                                              (30000, 16, 5, "dayhoff"), (20000, 10, 200, "protein")])
 def test_index_build_paths_agree(ctx, monkeypatch, nt, k, scaled, mol):
     """The index is built in three passes (two partition passes on a sort prefix + an in-LDS bucket sort: no bucket,
     one partition pass or two, depending on the size) with the 8-pass LSD sort as the fallback for skewed hashes:
@@ -428,7 +428,7 @@ def test_index_build_paths_agree(ctx, monkeypatch, nt, k, scaled, mol):
     monkeypatch.delenv("KS_DEBUG_INDEX_LSD")
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
-    if nt <= 2500:
+    if nt <= 2500 or scaled >= 100:
         to, tm, ta = T.to_host()
         qo, qm, _ = Q.to_host()
         want = oracle.manysearch(qo, qm, to, tm, ta, n_threads=8)
