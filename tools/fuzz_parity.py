@@ -1,0 +1,124 @@
+"""Randomised differential test of the HIP path against the oracle (sketch, k-mer positions, search).
+
+    python tools/fuzz_parity.py [--cases N] [--seed S]
+
+Every case draws k, scaled, moltype, a length distribution (peptides / proteome-like / long / degenerate), an alphabet
+(full, 2-letter, single residue, with ambiguity codes and lower case) and a batch size, sketches it through the C ABI and
+compares with the oracle bit for bit; every third case also builds an index and searches it.  Prints one line per failure.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+import kmerseek_amd as ks
+from oracle import oracle
+
+ALPHABETS = [b"ACDEFGHIKLMNPQRSTVWY", b"AC", b"A", b"ACDEFGHIKLMNPQRSTVWYXUO*BZJ", b"acdefghiklmnpqrstvwyACDEFG", b"LLLLLLLLLS"]
+
+
+def draw_batch(rng):
+    kind = rng.integers(0, 6)
+    n = int(rng.integers(1, 400))
+    if kind == 0:
+        lens = rng.integers(0, 40, n)
+    elif kind == 1:
+        lens = np.clip(np.rint(rng.lognormal(np.log(260.0), 0.55, n)), 0, 3000)
+    elif kind == 2:
+        lens = rng.integers(700, 4200, max(1, n // 8))
+    elif kind == 3:
+        lens = rng.choice([0, 1, 5, 4079, 4080, 4081, 8200, 300], size=max(1, n // 10))
+    elif kind == 4:
+        lens = rng.integers(0, 12, n * 4)
+    else:
+        lens = np.concatenate([rng.integers(0, 300, n), [int(rng.integers(5000, 30000))]])
+        rng.shuffle(lens)
+    lens = lens.astype(np.uint64)
+    offs = np.zeros(len(lens) + 1, np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    alpha = np.frombuffer(ALPHABETS[int(rng.integers(0, len(ALPHABETS)))], np.uint8)
+    res = rng.choice(alpha, size=int(offs[-1])).astype(np.uint8)
+    if rng.random() < 0.3 and len(res) > 50:  # planted repeats: abundances > 1, heavy buckets
+        unit = res[:int(rng.integers(3, 40))]
+        reps = np.tile(unit, len(res) // len(unit) + 1)[:len(res)]
+        mask = rng.random(len(res)) < 0.5
+        res = np.where(mask, reps, res).astype(np.uint8)
+    return res, offs
+
+
+def run(cases: int, seed: int) -> int:
+    """Runs `cases` random cases; prints one line per failure; returns the number of failures."""
+    rng = np.random.default_rng(seed)
+    ctx = ks.Context(0)
+    bad = 0
+    for case in range(cases):
+        k = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 10, 15, 16, 17, 21, 24, 31, 32, 33, 48, 64, 100, 128]))
+        scaled = int(rng.choice([1, 1, 1, 2, 5, 10, 50, 1000]))
+        mol = str(rng.choice(["protein", "dayhoff", "hp"]))
+        res, offs = draw_batch(rng)
+        tag = f"case {case}: k={k} scaled={scaled} {mol} n_seqs={len(offs) - 1} n_res={len(res)}"
+        try:
+            S = ctx.sketch_batch(res, offs, k, scaled, mol)
+            got = S.to_host()
+            want = oracle.sketch_batch(res, offs, k, scaled, mol, n_threads=8)
+            if not all(np.array_equal(g, w) for g, w in zip(got, want)):
+                print("SKETCH MISMATCH", tag); bad += 1; continue
+            # (process_kmers hashes the validated, already upper-case sequence as given — src/rust/index.rs:749-786 — so the
+            # oracle's position pass does not fold case; lower-case input never reaches it in the reference)
+            if case % 4 == 1 and len(res) < 200000 and not np.any((res >= 97) & (res <= 122)):
+                ps, pst, ph = ctx.kmer_positions(res, offs, k, scaled, mol)
+                o, mins, _ = want
+                ws, wst, wh = [], [], []
+                for i in range(len(offs) - 1):
+                    st, hh = oracle.kmer_positions(bytes(res[int(offs[i]):int(offs[i + 1])]), k, mol, mins[int(o[i]):int(o[i + 1])])
+                    ws.append(np.full(len(st), i, np.uint32)); wst.append(st); wh.append(hh)
+                if not (np.array_equal(ps, np.concatenate(ws)) and np.array_equal(pst, np.concatenate(wst)) and np.array_equal(ph, np.concatenate(wh))):
+                    ws_, wst_, wh_ = np.concatenate(ws), np.concatenate(wst), np.concatenate(wh)
+                    m = min(len(ps), len(ws_))
+                    d = np.nonzero((ps[:m] != ws_[:m]) | (pst[:m] != wst_[:m]) | (ph[:m] != wh_[:m]))[0]
+                    j = int(d[0]) if len(d) else m
+                    ctxt = ""
+                    if j < len(ws_):
+                        sq, st0 = int(ws_[j]), int(wst_[j])
+                        ctxt = f" want(seq={sq},start={st0},h={int(wh_[j])}) window={bytes(res[int(offs[sq]) + st0:int(offs[sq]) + st0 + k])!r} seqlen={int(offs[sq + 1] - offs[sq])} seqoff={int(offs[sq])}"
+                    if j < len(ps):
+                        ctxt += f" got(seq={int(ps[j])},start={int(pst[j])},h={int(ph[j])})"
+                    print("POSITIONS MISMATCH", tag, f"n_got={len(ps)} n_want={len(ws_)} first_diff={j}" + ctxt); bad += 1; continue
+            if case % 3 == 0:
+                res2, offs2 = draw_batch(rng)
+                if rng.random() < 0.5 and len(offs) > 2:  # make the queries overlap the targets
+                    cut = int(offs[len(offs) // 2])
+                    res2 = np.concatenate([res[:cut], res2]).astype(np.uint8)
+                    offs2 = np.concatenate([offs[:len(offs) // 2], offs2 + np.uint64(cut)]).astype(np.uint64)
+                Q = ctx.sketch_batch(res2, offs2, k, scaled, mol)
+                ix = ctx.index_build(S)
+                h = ctx.search(ix, Q).to_host()
+                qo, qm, _ = Q.to_host()
+                w = oracle.manysearch(qo, qm, want[0], want[1], want[2], n_threads=8)
+                if not all(np.array_equal(x, y) for x, y in zip(h, w)):
+                    print("SEARCH MISMATCH", tag, f"n_q={len(offs2) - 1} hits={len(h[0])}/{len(w[0])}"); bad += 1; continue
+                d_res, d_off = ctx.to_device(res2), ctx.to_device(offs2)
+                Q2 = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(offs2) - 1, len(res2))
+                h2 = ctx.search(ix, Q2).to_host()
+                if not all(np.array_equal(x, y) for x, y in zip(h2, w)):
+                    print("FUSED SEARCH MISMATCH", tag); bad += 1; continue
+        except Exception as e:  # noqa: BLE001
+            print("ERROR", tag, repr(e)); bad += 1
+    ctx.close()
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    bad = run(a.cases, a.seed)
+    print(f"{a.cases} cases, {bad} failures")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
