@@ -438,9 +438,15 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
     const u32 tid = threadIdx.x;
     u64 tile_base;
     u32 nvalid;
-    rs_tile_geom(0, seg_len, seg_cap, tiles_per_seg, tile_base, nvalid);
+    const u32 bid = ks_xcd_block(); // neighbouring tiles (whose runs meet in the same cache lines) share one L2
+    {
+        const u32 r = bid / tiles_per_seg, j = bid % tiles_per_seg;
+        const u64 len = seg_len[r], off = (u64)j * RS_TILE;
+        nvalid = off < len ? (u32)((len - off) < RS_TILE ? (len - off) : RS_TILE) : 0u;
+        tile_base = (u64)r * seg_cap + off;
+    }
     if (nvalid == 0) return; // tile beyond the region's fill (uniform per block)
-    const u32 region = blockIdx.x / tiles_per_seg;
+    const u32 region = bid / tiles_per_seg;
     if (tid < 256) cnt[tid] = 0;
     u64 key[RS_IPT];
     u32 val[RS_IPT];
