@@ -123,6 +123,9 @@ struct ks_sketches {
     u32 part_regions;
     int part_pbits;
     u32 part_K;     // ks_join_prefix multiplier the regions were cut with
+    // each region is split into 2^part_sub_shift sub-regions, one per XCD of the sketch launch (segment r << shift | x
+    // at (r << shift | x) * part_cap, part_len likewise): slices that are neighbours in memory were written through ONE L2
+    u32 part_sub_shift;
 };
 
 struct ks_index {
@@ -173,7 +176,8 @@ enum { KS_SORT_INDEX = 0, KS_SORT_QPART = 1, KS_SORT_PAIRS = 2 };
 struct ks_rs_segments {
     const u32 *len; // device
     u64 cap;
-    u32 regions;
+    u32 regions;    // number of segments
+    u32 sub_shift;  // partition digit of segment s = s >> sub_shift (sub-regions of one region share it)
 };
 int ks_radix_sort_u32(ks_ctx *ctx, int tag, const u64 *keys_in, const u32 *vals_in, u64 *ka, u32 *va, u64 *kb, u32 *vb,
                       u64 n, const int *shifts, int n_shifts, u64 **keys_out, u32 **vals_out,

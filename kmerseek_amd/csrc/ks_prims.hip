@@ -428,7 +428,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
 __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout,
                                                                         int shift, const u32 *seg_len, u64 seg_cap,
                                                                         u32 tiles_per_seg, u32 *bcur, u32 bcap,
-                                                                        unsigned long long *status, u32 pfxK, u32 n_hi) {
+                                                                        unsigned long long *status, u32 pfxK, u32 n_hi, u32 sub_shift) {
     __shared__ u32 cnt[256];
     __shared__ u32 dstart[256];
     __shared__ u32 gbase[256];
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
         tile_base = (u64)r * seg_cap + off;
     }
     if (nvalid == 0) return; // tile beyond the region's fill (uniform per block)
-    const u32 region = bid / tiles_per_seg;
+    const u32 region = (bid / tiles_per_seg) >> sub_shift;
     if (tid < 256) cnt[tid] = 0;
     u64 key[RS_IPT];
     u32 val[RS_IPT];
@@ -851,7 +851,7 @@ int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, c
     const u32 nblocks = seg->regions * tiles_per_seg;
     ks_timer_begin(ctx, "bucket_scatter");
     hipLaunchKernelGGL(k_bucket_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in, bkeys, bvals, shift,
-                       seg->len, seg->cap, tiles_per_seg, bcur, bcap, status, pfxK, n_hi);
+                       seg->len, seg->cap, tiles_per_seg, bcur, bcap, status, pfxK, n_hi, seg->sub_shift);
     ks_timer_end(ctx);
     KS_HIP(ctx, hipGetLastError());
     return KS_OK;

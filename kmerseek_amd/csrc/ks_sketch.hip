@@ -93,6 +93,7 @@ struct sk_args {
     u32 *part_cursor; // [256] records placed per region so far
     u64 part_cap;
     u32 part_K, part_mask; // region = ks_join_prefix(h, part_K) & part_mask
+    u32 part_sub_shift;    // sub-regions per region = 1 << shift; a workgroup writes sub-region blockIdx.x & (that - 1)
 };
 
 #define SK_FLAG_AGG (1ULL << 62)
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
                 if (tid < 256) {
                     u32 off = 0;
                     if (c) {
-                        off = atomicAdd(&A.part_cursor[tid], c);
+                        off = atomicAdd(&A.part_cursor[(tid << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u))], c);
                         if ((u64)off + c > A.part_cap) atomicOr(&A.ticket[1], 2u); // region full: host falls back
                     }
                     gbase[tid] = off;
@@ -614,8 +615,10 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
                 const u32 dg = ks_join_prefix(hh, A.part_K) & A.part_mask;
                 const u64 slot = (u64)gbase[dg] + (i - bins[dg]);
                 if (slot < A.part_cap) {
-                    A.part_keys[(u64)dg * A.part_cap + slot] = hh;
-                    A.part_vals[(u64)dg * A.part_cap + slot] = s_first + qrel[i];
+                    // (workgroups go round-robin to the XCDs, so blockIdx.x & 7 names the L2 these writes go through)
+                    const u64 at = (u64)((dg << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u))) * A.part_cap + slot;
+                    A.part_keys[at] = hh;
+                    A.part_vals[at] = s_first + qrel[i];
                 }
             }
         }
@@ -797,7 +800,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
 __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u64 *offs, const u64 *csr, const u64 *lg_hash,
                                                     const u32 *lg_abund, u64 *hashes, u32 *abunds, u64 *part_keys,
                                                     u32 *part_vals, u32 *part_cursor, u64 part_cap, u32 part_K,
-                                                    u32 part_mask, u32 *status) {
+                                                    u32 part_mask, u32 part_sub_shift, u32 *status) {
     const u32 s = ids[blockIdx.x];
     const u64 dst = csr[s], n = csr[s + 1] - dst, src = offs[s];
     for (u64 i = threadIdx.x; i < n; i += 256) {
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u64 *o
         hashes[dst + i] = h;
         abunds[dst + i] = lg_abund[src + i];
         if (part_keys) { // long sequences are rare: one device atomic per posting is fine here
-            const u32 dg = ks_join_prefix(h, part_K) & part_mask;
+            const u32 dg = ((ks_join_prefix(h, part_K) & part_mask) << part_sub_shift) | (blockIdx.x & ((1u << part_sub_shift) - 1u));
             const u64 slot = atomicAdd(&part_cursor[dg], 1u);
             if (slot < part_cap) {
                 part_keys[(u64)dg * part_cap + slot] = h;
@@ -1187,16 +1190,20 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             S->part_pbits = part_pbits;
             S->part_K = ks_join_prefix_mul(part_pbits, A.max_hash);
             S->part_regions = 1u << dbits;
-            const u64 per = S->n_windows / p->scaled / S->part_regions + 1; // FracMinHash keeps ~1/scaled of the windows
+            // one sub-region per XCD when a second partition pass follows (its tiles are per-segment anyway); when the
+            // regions ARE the join buckets (<= 8 prefix bits) they must stay contiguous
+            S->part_sub_shift = part_pbits > 8 ? 3u : 0u;
+            const u32 n_segs = S->part_regions << S->part_sub_shift;
+            const u64 per = S->n_windows / p->scaled / n_segs + 1; // FracMinHash keeps ~1/scaled of the windows
             u64 cap = per + per / 4 + 8192;                 // uniform hashes fill regions evenly; skew -> fallback
             cap = (cap + 8191) / 8192 * 8192;
             S->part_cap = cap;
-            SK_CHECK(ks_alloc(ctx, &S->part_keys, (size_t)(cap * S->part_regions)));
-            SK_CHECK(ks_alloc(ctx, &S->part_vals, (size_t)(cap * S->part_regions)));
-            SK_CHECK(ks_alloc(ctx, &S->part_len, 256));
-            SK_HIPCHECK(hipMemsetAsync(S->part_len, 0, 256 * sizeof(u32), ctx->stream));
+            SK_CHECK(ks_alloc(ctx, &S->part_keys, (size_t)(cap * n_segs)));
+            SK_CHECK(ks_alloc(ctx, &S->part_vals, (size_t)(cap * n_segs)));
+            SK_CHECK(ks_alloc(ctx, &S->part_len, 2048));
+            SK_HIPCHECK(hipMemsetAsync(S->part_len, 0, 2048 * sizeof(u32), ctx->stream));
             A.part_keys = S->part_keys; A.part_vals = S->part_vals; A.part_cursor = S->part_len; A.part_cap = cap;
-            A.part_K = S->part_K; A.part_mask = S->part_regions - 1;
+            A.part_K = S->part_K; A.part_mask = S->part_regions - 1; A.part_sub_shift = S->part_sub_shift;
         }
 
         // ---- medium / long sequences first: their unique counts feed the tile kernel's CSR prefix
@@ -1265,14 +1272,14 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             // medium runs: copy only (their tiles emitted their own postings)
             hipLaunchKernelGGL(k_place_long, dim3((u32)n_med), dim3(256), 0, ctx->stream, (const u32 *)med_ids, d_offs,
                                (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds,
-                               (u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u64)0, 0u, 0u, ticket);
+                               (u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u64)0, 0u, 0u, 0u, ticket);
             ks_timer_end(ctx);
         }
         if (n_long > 0) {
             ks_timer_begin(ctx, "place_long");
             hipLaunchKernelGGL(k_place_long, dim3((u32)n_long), dim3(256), 0, ctx->stream, (const u32 *)long_ids, d_offs,
                                (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds,
-                               A.part_keys, A.part_vals, A.part_cursor, A.part_cap, A.part_K, A.part_mask, ticket);
+                               A.part_keys, A.part_vals, A.part_cursor, A.part_cap, A.part_K, A.part_mask, A.part_sub_shift, ticket);
             ks_timer_end(ctx);
         }
         SK_HIPCHECK(hipGetLastError());

@@ -44,9 +44,11 @@ def proteome(n_seqs: int, stream: int = 0, lo: int = 30, hi: int = 3000) -> Tupl
 
 
 def queries(n_queries: int, index_res: np.ndarray, index_offs: np.ndarray, stream: int = 1,
-            frac_related: float = 0.2, p_sub: float = 0.10, p_indel: float = 0.01
+            frac_related: float = 0.2, p_sub: float = 0.10, p_indel: float = 0.01, shuffle: bool = True
             ) -> Tuple[np.ndarray, np.ndarray]:
-    """Query set: frac_related mutated copies of random index proteins, the rest independent."""
+    """Query set: frac_related mutated copies of random index proteins, the rest independent, in random order
+    (shuffle=False leaves the related ones first — which flatters the join: all matches then sit in the same few
+    registers of a workgroup)."""
     rng = np.random.Generator(np.random.PCG64(BASE_SEED + stream))
     n_rel = int(round(n_queries * frac_related))
     n_ind = n_queries - n_rel
@@ -78,8 +80,29 @@ def queries(n_queries: int, index_res: np.ndarray, index_offs: np.ndarray, strea
     # --- independent proteins
     lens_ind = lengths(rng, n_ind).astype(np.int64)
     ind_res = _residues(rng, int(lens_ind.sum()))
-    # --- related queries first, then the independent ones (no shuffle: a 300M-element gather buys nothing)
     all_len = np.concatenate([new_len, lens_ind]).astype(np.uint64)
     offs = np.zeros(n_queries + 1, dtype=np.uint64)
     np.cumsum(all_len, out=offs[1:])
-    return np.concatenate([out_res, ind_res]), offs
+    all_res = np.concatenate([out_res, ind_res])
+    if not shuffle or n_queries < 2:
+        return all_res, offs
+    perm = rng.permutation(n_queries)
+    p_len = all_len[perm].astype(np.int64)
+    p_offs = np.zeros(n_queries + 1, dtype=np.uint64)
+    np.cumsum(p_len.astype(np.uint64), out=p_offs[1:])
+    # gather in slabs of sequences to bound the index arrays (a 1M-protein set is 300M residues)
+    out = np.empty(int(p_offs[-1]), dtype=np.uint8)
+    step = 100_000
+    for lo in range(0, n_queries, step):
+        hi = min(lo + step, n_queries)
+        ln = p_len[lo:hi]
+        tot_l = int(ln.sum())
+        if tot_l == 0:
+            continue
+        dst0 = int(p_offs[lo])
+        starts_l = np.zeros(hi - lo, dtype=np.int64)
+        np.cumsum(ln[:-1], out=starts_l[1:])
+        src0 = offs[perm[lo:hi]].astype(np.int64)
+        idx = np.arange(tot_l, dtype=np.int64) - np.repeat(starts_l, ln) + np.repeat(src0, ln)
+        out[dst0:dst0 + tot_l] = all_res[idx]
+    return out, p_offs

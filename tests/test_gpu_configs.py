@@ -64,12 +64,12 @@ def test_config3_100k_vs_100k_dayhoff_k16_s5(ctx):
     qid, tid, isect, nw = got
     key = qid.astype(np.uint64) << np.uint64(32) | tid.astype(np.uint64)
     assert np.all(key[1:] > key[:-1])
-    sample = list(range(0, 20000, 97)) + list(range(20000, 100000, 1999))  # related queries come first
+    sample = list(range(0, 100000, 211))  # one query in five is a mutated copy of a target, in random order
     oq, ot, oi, ow = oracle_hits_for(want_q, want_t, sample)
     sel = np.isin(qid, np.asarray(sample, np.uint32))
     assert np.array_equal(qid[sel], oq) and np.array_equal(tid[sel], ot)
     assert np.array_equal(isect[sel], oi) and np.array_equal(nw[sel], ow)
-    assert len(oq) > 150
+    assert len(oq) > 60
 
 
 def test_config5_all_vs_all_hp_k24_sharded(ctx):

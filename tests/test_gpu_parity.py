@@ -354,11 +354,13 @@ def test_presorted_query_postings_equal_plain_search(ctx, k, scaled, mol, nt, nq
 
 
 def test_presorted_postings_fall_back_on_skewed_hashes(ctx):
-    """20000 copies of one protein: ~290 distinct hashes land in a few of the 256 fixed-size regions and overflow them.
-    The postings are dropped, the sketches are still exactly right, and ks_search partitions from the CSR instead."""
+    """120000 copies of one protein: ~290 distinct hashes land in a few of the 256 fixed-size regions (8 per-XCD
+    sub-regions each) and overflow those that receive three or more of them.  The postings are dropped, the sketches are
+    still exactly right, and ks_search partitions from the CSR instead."""
     t_res, t_off = synth.proteome(30000, stream=95)
     one = bytes(t_res[int(t_off[7]):int(t_off[8])])
-    q_res, q_off = ks.pack([one] * 20000)
+    N = 120000
+    q_res, q_off = ks.pack([one] * N)
     T = ctx.sketch_batch(t_res, t_off, 10, 1, "protein")
     ix = ctx.index_build(T)
     d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
@@ -367,11 +369,11 @@ def test_presorted_postings_fall_back_on_skewed_hashes(ctx):
     o, m, a = Q.to_host()
     w1 = oracle.sketch_protein(one, 10, 1, "protein")
     n1 = len(w1[0])
-    assert np.array_equal(o, np.arange(20001, dtype=np.uint64) * np.uint64(n1))
-    assert np.array_equal(m.reshape(20000, n1), np.tile(w1[0], (20000, 1)))
+    assert np.array_equal(o, np.arange(N + 1, dtype=np.uint64) * np.uint64(n1))
+    assert np.array_equal(m.reshape(N, n1), np.tile(w1[0], (N, 1)))
     qid, tid, isect, nw = ctx.search(ix, Q).to_host()
     self_hits = tid == 7
-    assert self_hits.sum() == 20000 and np.all(isect[self_hits] == n1)
+    assert self_hits.sum() == N and np.all(isect[self_hits] == n1)
 
 
 def test_bucket_scatter_overflow_falls_back_to_dense_partition(ctx):
