@@ -148,6 +148,9 @@ done:
 #define JN_E 12
 #endif
 //                     JN_E query postings per thread per round: 12 independent fixed-trip LDS searches in flight
+#ifndef JN_WLIST
+#define JN_WLIST 128
+#endif
 #ifndef JN_FILLU
 #define JN_FILLU 6
 #endif
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
                                                              u32 *pair_vals, u64 cap, unsigned long long *cursor,
                                                              int tbits, int abits) {
     __shared__ u64 lk[JN_CAP];
+    __shared__ u32 wlist[JN_THREADS / 64][JN_WLIST]; // per-wave list of the round's pairs (query | index posting << 13)
     __shared__ u32 scan_smem[JN_THREADS / 64 + 1];
     __shared__ unsigned long long base_s;
     const u32 tid = threadIdx.x;
@@ -277,27 +281,54 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
             if (total) { // uniform
                 if (tid == 0) base_s = atomicAdd(cursor, (unsigned long long)total); // (64 sharded cursors measured no faster)
                 __syncthreads();
-                u64 slot = base_s + off;
                 // Matches are sparse (a few per cent of the queries) and sit anywhere among a thread's JN_E queries: walking
-                // e = 0..JN_E-1 would run JN_E rounds of memory operations with a handful of lanes active in each.  Every
-                // thread walks ITS OWN matches instead (lowest e first, so the slot order is unchanged): the wave finishes in
-                // max-over-lanes(matches) rounds, ~3 instead of 12, with several times the lanes active in each.
-                while (hit) {
-                    const int e = __builtin_ctz(hit);
-                    hit &= hit - 1;
-                    u32 inf = info[0];
+                // e = 0..JN_E-1 would run JN_E rounds of memory operations with a handful of lanes active in each.  Instead
+                // every thread walks ITS OWN matches (lowest e first: slot order unchanged), and — when the wave's matches
+                // fit its LDS list — only to LIST them: one 4-byte entry (query, index posting) per pair at the pair's
+                // position inside the wave's slice, so that afterwards lane k emits pair k: full lanes, contiguous stores.
+                const u32 lane = tid & 63u, wave = tid >> 6;
+                const u32 wbase = __shfl(off, 0, 64);                           // first pair of this wave inside the round
+                const u32 wtotal = __shfl(off + mine, 63, 64) - wbase;          // pairs of this wave
+                if (wtotal <= JN_WLIST) { // uniform per wave
+                    u32 p = off - wbase;
+                    while (hit) {
+                        const int e = __builtin_ctz(hit);
+                        hit &= hit - 1;
+                        u32 inf = info[0];
 #pragma unroll
-                    for (int k = 1; k < JN_E; k++) inf = e == k ? info[k] : inf; // (register array: select, no indexing)
-                    const u32 c = inf >> 16;
-                    {
-                        const u64 i = q0 + (u64)e * JN_THREADS + tid;
-                        const u32 q = qids[i];
+                        for (int k = 1; k < JN_E; k++) inf = e == k ? info[k] : inf; // (register array: select, no indexing)
+                        const u32 c = inf >> 16, qi = (u32)e * JN_THREADS + tid, pos = inf & 0xffffu;
+                        for (u32 j = 0; j < c; j++) wlist[wave][p++] = qi | ((pos + j) << 13);
+                    }
+                    __builtin_amdgcn_wave_barrier(); // same wave: LDS operations execute in order
+                    for (u32 k = lane; k < wtotal; k += 64) {
+                        const u32 en = wlist[wave][k];
+                        const u64 slot = base_s + wbase + k;
+                        if (slot < cap) {
+                            const u32 q = qids[q0 + (en & 0x1fffu)];
+                            const u64 jp = c0 + (en >> 13);
+                            const u64 ids = ((u64)q << tbits) | itids[jp]; // ids packed tight: fewer sort passes
+                            if (pair_vals) { pair_keys[slot] = ids; pair_vals[slot] = iabunds[jp]; }
+                            else pair_keys[slot] = (ids << abits) | iabunds[jp]; // one 8-byte record per match
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                } else { // a hash shared by many targets: emit straight from the registers
+                    u64 slot = base_s + off;
+                    while (hit) {
+                        const int e = __builtin_ctz(hit);
+                        hit &= hit - 1;
+                        u32 inf = info[0];
+#pragma unroll
+                        for (int k = 1; k < JN_E; k++) inf = e == k ? info[k] : inf;
+                        const u32 c = inf >> 16;
+                        const u32 q = qids[q0 + (u64)e * JN_THREADS + tid];
                         const u64 j0 = c0 + (inf & 0xffffu);
                         for (u32 j = 0; j < c; j++, slot++) {
                             if (slot < cap) {
-                                const u64 ids = ((u64)q << tbits) | itids[j0 + j]; // ids packed tight: fewer sort passes
+                                const u64 ids = ((u64)q << tbits) | itids[j0 + j];
                                 if (pair_vals) { pair_keys[slot] = ids; pair_vals[slot] = iabunds[j0 + j]; }
-                                else pair_keys[slot] = (ids << abits) | iabunds[j0 + j]; // one 8-byte record per match
+                                else pair_keys[slot] = (ids << abits) | iabunds[j0 + j];
                             }
                         }
                     }
