@@ -62,10 +62,11 @@ KS_DEV u64 ks_mask_bytes(u32 n) { return n >= 8 ? ~0ULL : ((1ULL << (8 * n)) - 1
 // tiles touch the same cache lines (partition scatters: a tile's digit runs end where the next tile's begin) take their
 // tile id from this instead of blockIdx.x: XCD x works through a contiguous eighth of the tiles, so the lines two tiles
 // share are assembled in ONE L2 (measured on the bucket scatter: 1.58 -> 1.29 ms, and the join that reads its output
-// 2.17 -> 1.80 ms).  A bijection on [0, gridDim.x) whenever the grid is a multiple of 8, the identity otherwise.
+// 2.17 -> 1.80 ms).  A bijection on [0, gridDim.x) for any grid size: XCD x = b & 7 owns g/8 tiles (one more for the
+// first g%8 XCDs), its j-th workgroup (j = b >> 3) takes the j-th of them.
 KS_DEV u32 ks_xcd_block() {
-    const u32 b = blockIdx.x, g = gridDim.x;
-    return (g & 7u) == 0 ? (b & 7u) * (g >> 3) + (b >> 3) : b;
+    const u32 b = blockIdx.x, g = gridDim.x, x = b & 7u, q = g >> 3, rem = g & 7u;
+    return x * q + (x < rem ? x : rem) + (b >> 3);
 }
 
 // ---- wave / block exclusive scans (u32) ----

@@ -277,14 +277,14 @@ int ks_scan_u32_inplace(ks_ctx *ctx, u32 *data, u64 n, u32 *d_total) {
 // Input geometry of a pass.  Dense: tile b covers records [b*RS_TILE, ...) of n.  Segmented (seg_len != NULL): the
 // input is a set of fixed-capacity regions (region r holds seg_len[r] records from r*seg_cap on) and tile b is the
 // (b % tiles_per_seg)-th tile of region b / tiles_per_seg — how the sketch kernel's pre-partitioned postings enter.
-KS_DEV void rs_tile_geom(u64 n, const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg, u64 &in_base, u32 &nvalid) {
+KS_DEV void rs_tile_geom(u32 bid, u64 n, const u32 *seg_len, u64 seg_cap, u32 tiles_per_seg, u64 &in_base, u32 &nvalid) {
     if (seg_len) {
-        const u32 r = blockIdx.x / tiles_per_seg, j = blockIdx.x % tiles_per_seg;
+        const u32 r = bid / tiles_per_seg, j = bid % tiles_per_seg;
         const u64 len = seg_len[r], off = (u64)j * RS_TILE;
         nvalid = off < len ? (u32)((len - off) < RS_TILE ? (len - off) : RS_TILE) : 0u;
         in_base = (u64)r * seg_cap + off;
     } else {
-        in_base = (u64)blockIdx.x * RS_TILE;
+        in_base = (u64)bid * RS_TILE;
         const u64 remain = n - in_base;
         nvalid = remain < RS_TILE ? (u32)remain : RS_TILE;
     }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 
     __syncthreads();
     u64 base;
     u32 nvalid;
-    rs_tile_geom(n, seg_len, seg_cap, tiles_per_seg, base, nvalid);
+    rs_tile_geom(blockIdx.x, n, seg_len, seg_cap, tiles_per_seg, base, nvalid);
 #pragma unroll
     for (int i = 0; i < RS_IPT; i++) {
         const u32 li = (u32)i * RS_THREADS + threadIdx.x;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
 
     u64 tile_base;
     u32 nvalid;
-    rs_tile_geom(n, seg_len, seg_cap, tiles_per_seg, tile_base, nvalid);
+    rs_tile_geom(blockIdx.x, n, seg_len, seg_cap, tiles_per_seg, tile_base, nvalid);
     const u32 wloc = wave * (64 * RS_IPT); // this wave's first record inside the tile
     u64 key[RS_IPT];
     V val[RS_IPT];
@@ -540,9 +540,12 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_part_scatter64(const u6
     const u32 tid = threadIdx.x;
     u64 tile_base;
     u32 nvalid;
-    rs_tile_geom(n, seg_len, seg_cap, tiles_per_seg, tile_base, nvalid);
+    // second pass (segmented input): all tiles of a region go to one XCD, so the slices that meet in a bucket's cache
+    // lines are assembled in one L2 (2.99 -> 2.44 ms); the first pass reserves slices in arrival order: nothing to gain
+    const u32 bid = seg_len ? ks_xcd_block() : blockIdx.x;
+    rs_tile_geom(bid, n, seg_len, seg_cap, tiles_per_seg, tile_base, nvalid);
     if (nvalid == 0) return;
-    const u32 region = seg_len ? blockIdx.x / tiles_per_seg : 0u;
+    const u32 region = seg_len ? bid / tiles_per_seg : 0u;
     cnt[tid] = 0;
     u64 key[RS_IPT];
     u64 val[RS_IPT];
