@@ -110,12 +110,63 @@ def run(cases: int, seed: int) -> int:
     return bad
 
 
+def run_big(cases: int, seed: int) -> int:
+    """Batches of 5k-60k proteins (many tiles, look-back chains, full partition paths): sketch vs oracle; search by the
+    fused path (postings from the sketch kernel) vs the plain path, and partitioned vs LSD index build — GPU vs GPU,
+    the pairwise oracle search is quadratic."""
+    from kmerseek_amd import synth
+    rng = np.random.default_rng(seed)
+    ctx = ks.Context(0)
+    bad = 0
+    for case in range(cases):
+        k = int(rng.choice([5, 7, 10, 16, 21, 24, 32]))
+        scaled = int(rng.choice([1, 1, 2, 5, 20]))
+        mol = str(rng.choice(["protein", "dayhoff", "hp"]))
+        if mol == "hp" and k < 16:
+            k = 16  # 2-letter alphabet: below ~16 every protein shares every k-mer and the match list exceeds its 2^32 cap
+        nt, nq = int(rng.integers(5000, 60000)), int(rng.integers(5000, 60000))
+        t_res, t_off = synth.proteome(nt, stream=5000 + case, hi=int(rng.choice([300, 3000, 9000])))
+        q_res, q_off = synth.queries(nq, t_res, t_off, stream=6000 + case, frac_related=float(rng.choice([0.0, 0.2, 0.9])))
+        tag = f"big case {case}: k={k} scaled={scaled} {mol} nt={nt} nq={nq}"
+        try:
+            T = ctx.sketch_batch(t_res, t_off, k, scaled, mol)
+            if not all(np.array_equal(g, w) for g, w in zip(T.to_host(), oracle.sketch_batch(t_res, t_off, k, scaled, mol, n_threads=16))):
+                print("SKETCH MISMATCH", tag); bad += 1; continue
+            ix = ctx.index_build(T)
+            Q = ctx.sketch_batch(q_res, q_off, k, scaled, mol)
+            plain = ctx.search(ix, Q).to_host()
+            d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
+            Qf = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, nq, len(q_res))
+            fused = ctx.search(ix, Qf).to_host()
+            os.environ["KS_DEBUG_INDEX_LSD"] = "1"
+            lsd = ctx.search(ctx.index_build(T), Q).to_host()
+            del os.environ["KS_DEBUG_INDEX_LSD"]
+            if not all(np.array_equal(x, y) for x, y in zip(plain, fused)):
+                print("FUSED != PLAIN", tag); bad += 1; continue
+            if not all(np.array_equal(x, y) for x, y in zip(plain, lsd)):
+                print("PARTITIONED INDEX != LSD INDEX", tag); bad += 1; continue
+            # oracle on a few queries
+            qo, qm, _ = Q.to_host()
+            to, tm, ta = T.to_host()
+            pick = rng.choice(nq, size=6, replace=False)
+            for qi in pick.tolist():
+                w = oracle.manysearch(np.array([0, qo[qi + 1] - qo[qi]], np.uint64), qm[int(qo[qi]):int(qo[qi + 1])], to, tm, ta, n_threads=16)
+                sel = plain[0] == qi
+                if not (np.array_equal(plain[1][sel], w[1]) and np.array_equal(plain[2][sel], w[2]) and np.array_equal(plain[3][sel], w[3])):
+                    print("SEARCH MISMATCH", tag, f"query {qi}"); bad += 1; break
+        except Exception as e:  # noqa: BLE001
+            print("ERROR", tag, repr(e)); bad += 1
+    ctx.close()
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--big", action="store_true", help="few large batches instead of many small ones")
     a = ap.parse_args()
-    bad = run(a.cases, a.seed)
+    bad = run_big(a.cases, a.seed) if a.big else run(a.cases, a.seed)
     print(f"{a.cases} cases, {bad} failures")
     sys.exit(1 if bad else 0)
 

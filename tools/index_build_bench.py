@@ -1,3 +1,4 @@
+"""Per-kernel timing of ks_index_build on a resident 1M-protein sketch (KS_DEBUG_INDEX_LSD=1 times the 8-pass fallback)."""
 import sys, time, json
 sys.path.insert(0, "/root/repo")
 import kmerseek_amd as ks
