@@ -148,6 +148,9 @@ done:
 #define JN_E 12
 #endif
 //                     JN_E query postings per thread per round: 12 independent fixed-trip LDS searches in flight
+// most records one match list may hold (32-bit offsets in the sort and the reduce); a debug override makes the
+// slicing path testable on small inputs
+#define KS_PAIR_LIMIT (getenv("KS_DEBUG_PAIR_LIMIT") ? strtoull(getenv("KS_DEBUG_PAIR_LIMIT"), nullptr, 10) : 0xfffffff0ULL)
 #ifndef JN_WLIST
 #define JN_WLIST 128
 #endif
@@ -398,7 +401,11 @@ __global__ __launch_bounds__(256) void k_pair_reduce(const u64 *keys, const u32 
     }
 }
 
-int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out) {
+// One search with the whole query batch in one match list.  *split_pairs != 0 on return (with KS_OK and *out == NULL) means
+// the list would hold that many records — more than one list can (2^32) — and nothing was produced: the caller splits.
+static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out, u64 *split_pairs) {
+    *split_pairs = 0;
+    *out = nullptr;
     if (!ix || !q || !out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     if (ix->params.ksize != q->params.ksize || ix->params.scaled != q->params.scaled ||
         ix->params.moltype != q->params.moltype || ix->params.seed != q->params.seed)
@@ -412,6 +419,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
     u32 *qv0 = nullptr, *qv1 = nullptr, *pv0 = nullptr, *pv1 = nullptr, *heads = nullptr, *d_nrows = nullptr, *bcur = nullptr;
     unsigned long long *cursor = nullptr;
     int st = KS_OK;
+    bool split = false;
 #define SE_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
 #define SE_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
     if (n_q == 0 || n_t == 0) {
@@ -512,8 +520,13 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
                 SE_HIP(hipStreamSynchronize(ctx->stream));
                 n_pairs = ctx->h_pin[0];
                 overflowed = way == 0 && ctx->h_pin[1] != 0;
+                if (!overflowed && n_pairs >= KS_PAIR_LIMIT) { // saturated alphabets: the caller searches the queries in slices
+                    *split_pairs = n_pairs;
+                    split = true;
+                    goto done;
+                }
                 if (overflowed || n_pairs <= cap) break;
-                if (attempt == 1 || n_pairs >= 0xfffffff0ULL) {
+                if (attempt == 1) {
                     st = ks_fail(ctx, KS_ERR_CAPACITY, "search produced %llu matched posting pairs (cap %llu)",
                                  (unsigned long long)n_pairs, (unsigned long long)cap);
                     goto done;
@@ -582,11 +595,93 @@ done:
     ks_pool_free(ctx, pk0); ks_pool_free(ctx, pk1); ks_pool_free(ctx, pv0); ks_pool_free(ctx, pv1);
     ks_pool_free(ctx, heads); ks_pool_free(ctx, d_nrows); ks_pool_free(ctx, row_start); ks_pool_free(ctx, cursor);
     ks_pool_free(ctx, dir_q); ks_pool_free(ctx, bcur);
-    if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_hits_free(H); return st; }
+    if (st != KS_OK || split) { (void)hipStreamSynchronize(ctx->stream); ks_hits_free(H); return st; }
     *out = H;
     return KS_OK;
 #undef SE_CHECK
 #undef SE_HIP
+}
+
+__global__ __launch_bounds__(256) void k_rebase_offsets(const u64 *offs, u64 base, u32 n, u64 *out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = offs[i] - base;
+}
+__global__ __launch_bounds__(256) void k_add_u32(u32 *a, u64 n, u32 v) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += v;
+}
+
+// ks_search: one match list when it fits; otherwise the query sequences are searched in contiguous slices whose lists
+// fit (a slice is a view of the batch's CSR: hits of different query ranges are disjoint and stay ordered by qid).
+int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out) {
+    if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    u64 need = 0;
+    int st = search_core(ctx, ix, q, out, &need);
+    if (st != KS_OK || need == 0) return st;
+    // ---- slices of roughly equal posting counts, each expected to produce KS_PAIR_LIMIT / 4 records
+    std::vector<u64> offs((size_t)q->n_seqs + 1);
+    KS_HIP(ctx, hipMemcpyAsync(offs.data(), q->d_offsets, offs.size() * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    u64 n_slices = need / (KS_PAIR_LIMIT / 4) + 1;
+    std::vector<ks_hits *> parts;
+    std::vector<u32> firsts;
+    auto cleanup = [&]() { for (auto *h : parts) ks_hits_free(h); };
+    u32 a = 0;
+    while (a < q->n_seqs) {
+        const u64 want = q->n_hashes / n_slices + 1;
+        u32 b = a + 1;
+        while (b < q->n_seqs && offs[b + 1] - offs[a] <= want) b++;
+        for (;;) { // search sequences [a, b); halve the slice while it still overflows
+            ks_sketches V;
+            memset(&V, 0, sizeof V);
+            V.ctx = ctx; V.params = q->params; V.n_seqs = b - a; V.n_hashes = offs[b] - offs[a]; V.n_windows = q->n_windows;
+            V.d_hashes = q->d_hashes + offs[a]; V.d_abunds = q->d_abunds + offs[a];
+            st = ks_alloc(ctx, &V.d_offsets, (size_t)V.n_seqs + 1);
+            if (st != KS_OK) { cleanup(); return st; }
+            hipLaunchKernelGGL(k_rebase_offsets, dim3((V.n_seqs + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)q->d_offsets + a, offs[a],
+                               V.n_seqs + 1, V.d_offsets);
+            ks_hits *h = nullptr;
+            u64 more = 0;
+            st = search_core(ctx, ix, &V, &h, &more);
+            (void)hipStreamSynchronize(ctx->stream);
+            ks_pool_free(ctx, V.d_offsets);
+            if (st != KS_OK) { cleanup(); return st; }
+            if (more == 0) { parts.push_back(h); firsts.push_back(a); break; }
+            if (b - a == 1) { cleanup(); return ks_fail(ctx, KS_ERR_CAPACITY, "one query sequence matches %llu postings: beyond the match-list limit", (unsigned long long)more); }
+            b = a + (b - a) / 2;
+            n_slices *= 2;
+        }
+        a = b;
+    }
+    // ---- concatenate (query ids back to batch numbering)
+    ks_hits *H = new ks_hits();
+    memset(H, 0, sizeof *H);
+    H->ctx = ctx;
+    H->partition_path = 3;
+    for (auto *h : parts) { H->n_hits += h->n_hits; H->n_pair_instances += h->n_pair_instances; }
+    const size_t tot = H->n_hits ? (size_t)H->n_hits : 1;
+    st = ks_alloc(ctx, &H->d_qid, tot);
+    if (st == KS_OK) st = ks_alloc(ctx, &H->d_tid, tot);
+    if (st == KS_OK) st = ks_alloc(ctx, &H->d_isect, tot);
+    if (st == KS_OK) st = ks_alloc(ctx, &H->d_nw, tot);
+    u64 at = 0;
+    for (size_t i = 0; i < parts.size() && st == KS_OK; i++) {
+        const u64 n = parts[i]->n_hits;
+        if (n) {
+            hipLaunchKernelGGL(k_add_u32, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, parts[i]->d_qid, n, firsts[i]);
+            if (hipMemcpyAsync(H->d_qid + at, parts[i]->d_qid, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(H->d_tid + at, parts[i]->d_tid, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(H->d_isect + at, parts[i]->d_isect, n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(H->d_nw + at, parts[i]->d_nw, n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                st = ks_fail(ctx, KS_ERR_HIP, "hit concatenation failed");
+            at += n;
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (st != KS_OK) { ks_hits_free(H); return st; }
+    *out = H;
+    return KS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

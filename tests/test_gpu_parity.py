@@ -459,3 +459,36 @@ def test_index_build_falls_back_on_duplicated_targets(ctx, monkeypatch):
     assert int((qid == 0).sum()) == 4000 and int((qid == 2).sum()) == 4000
     assert set(isect[qid == 2].tolist()) == {291} and set(isect[qid == 0].tolist()) == {141}
     assert tid[qid == 1].tolist() == [4003] and isect[qid == 1].tolist() == [len(other[3]) - 9]
+
+
+def test_search_slices_the_queries_when_the_match_list_is_too_long(ctx, monkeypatch):
+    """A match list holds at most 2^32 records; beyond that ks_search runs the query sequences in slices and
+    concatenates the hits.  With the limit lowered (debug knob) a 300 x 300-copies search (26 M matched postings) takes
+    that path: same hits as the single-list search, still ordered by (qid, tid)."""
+    rng = np.random.default_rng(12)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    prot = bytes(rng.choice(aa, size=300).tolist())
+    others = [bytes(rng.choice(aa, size=int(n)).tolist()) for n in rng.integers(40, 500, 200)]
+    t_res, t_off = ks.pack([prot] * 300 + others)
+    q_seqs = others[:50] + [prot] * 300 + others[50:120] + [b"", b"ACD"]
+    q_res, q_off = ks.pack(q_seqs)
+    T = ctx.sketch_batch(t_res, t_off, 10, 1, "protein")
+    Q = ctx.sketch_batch(q_res, q_off, 10, 1, "protein")
+    ix = ctx.index_build(T)
+    whole = ctx.search(ix, Q)
+    want = whole.to_host()
+    assert whole.n_pair_instances > 20_000_000
+    monkeypatch.setenv("KS_DEBUG_PAIR_LIMIT", "4000000")
+    sliced = ctx.search(ix, Q)
+    got = sliced.to_host()
+    monkeypatch.delenv("KS_DEBUG_PAIR_LIMIT")
+    assert sliced.n_pair_instances == whole.n_pair_instances
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    key = got[0].astype(np.uint64) << np.uint64(32) | got[1].astype(np.uint64)
+    assert np.all(key[1:] > key[:-1])
+    # a single query that cannot fit on its own is refused, not mangled
+    monkeypatch.setenv("KS_DEBUG_PAIR_LIMIT", "50000")
+    with pytest.raises(ks.KmerseekError):
+        ctx.search(ix, Q)
+    monkeypatch.delenv("KS_DEBUG_PAIR_LIMIT")
