@@ -145,9 +145,10 @@ done:
 #define JN_THREADS 512
 #endif
 #ifndef JN_E
-#define JN_E 12
+#define JN_E 10
 #endif
-//                     JN_E query postings per thread per round: 12 independent fixed-trip LDS searches in flight
+//                     JN_E query postings per thread per round (10: one round covers the ~4.5k queries of a bucket of the
+//                     1M-vs-1M workload with fewer registers than 12; 9 needs a second round for half of the buckets)
 // most records one match list may hold (32-bit offsets in the sort and the reduce); a debug override makes the
 // slicing path testable on small inputs
 #define KS_PAIR_LIMIT (getenv("KS_DEBUG_PAIR_LIMIT") ? strtoull(getenv("KS_DEBUG_PAIR_LIMIT"), nullptr, 10) : 0xfffffff0ULL)
