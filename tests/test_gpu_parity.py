@@ -492,3 +492,36 @@ def test_search_slices_the_queries_when_the_match_list_is_too_long(ctx, monkeypa
     with pytest.raises(ks.KmerseekError):
         ctx.search(ix, Q)
     monkeypatch.delenv("KS_DEBUG_PAIR_LIMIT")
+
+
+def test_sketch_repeats_with_ticket_ids_when_a_lookback_gives_up(monkeypatch):
+    """Tile ids normally come from blockIdx.x (dispatch order).  If a look-back ever gave up, the launch is repeated
+    with ids from an atomic ticket and the context keeps using the ticket: forced here, same sketches, same postings
+    (fused search), also with medium / long sequences in the batch."""
+    rng = np.random.default_rng(21)
+    t_res, t_off = synth.proteome(6000, stream=400)
+    q_res, q_off = synth.queries(5000, t_res, t_off, stream=401)
+    extra = [bytes(rng.choice(list(b"ACDEFGHIKLMNPQRSTVWY"), size=n).tolist()) for n in (1700, 4000, 4090, 9000, 20000)]
+    seqs = [bytes(q_res[int(q_off[i]):int(q_off[i + 1])]) for i in range(5000)]
+    q_res, q_off = ks.pack(seqs[:100] + extra[:3] + seqs[100:] + extra[3:])
+    want = oracle.sketch_batch(q_res, q_off, 10, 1, "protein", n_threads=8)
+    ctx = ks.Context(0)
+    try:
+        T = ctx.sketch_batch(t_res, t_off, 10, 1, "protein")
+        ix = ctx.index_build(T)
+        ref_hits = ctx.search(ix, ctx.sketch_batch(q_res, q_off, 10, 1, "protein")).to_host()
+        monkeypatch.setenv("KS_DEBUG_FORCE_TICKET_RETRY", "1")
+        d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
+        Q = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
+        monkeypatch.delenv("KS_DEBUG_FORCE_TICKET_RETRY")
+        for g, w in zip(Q.to_host(), want):
+            assert np.array_equal(g, w)
+        assert Q.has_postings
+        for g, w in zip(ctx.search(ix, Q).to_host(), ref_hits):
+            assert np.array_equal(g, w)
+        # the context now draws tickets: still right
+        Q2 = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
+        for g, w in zip(Q2.to_host(), want):
+            assert np.array_equal(g, w)
+    finally:
+        ctx.close()
