@@ -374,8 +374,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
 
     SK_STAMP_AT(4);
     // ---- phase 5: rank inside the bucket; first arrival of each distinct hash is its representative
-    u32 pr[SK_E]; // (sorted position << 1) | is_representative, or ~0
-    u32 ab[SK_E];
+    u32 pa[SK_E]; // abundance (later: rank inside the posting digit) << 16 | sorted position << 1 | is_representative; 0 = nothing
     // Buckets hold ~1 element: 3 out of 4 kept hashes sit in a bucket of size 1 or 2 and are ranked with at most one
     // LDS read.  The rest ("heavy": bucket of 3+) would make every wave iterate to ITS largest bucket in each of the
     // 8 slots, so they are queued (in the unused tail of tmp) and ranked by all threads evenly in a second pass.
@@ -399,8 +398,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     };
 #pragma unroll
     for (int i = 0; i < SK_E; i++) {
-        pr[i] = 0xffffffffu;
-        ab[i] = 0;
+        pa[i] = 0;
         if (bo[i] != 0xffffffffu) {
             const u32 b = SK_BO_B(bo[i]), o = SK_BO_O(bo[i]);
             const u32 sb = bstart(b), c = bstart(b + 1) - sb;
@@ -423,8 +421,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
                 }
             }
             if (done) {
-                pr[i] = (p << 1) | rep;
-                ab[i] = eq;
+                pa[i] = (eq << 16) | (p << 1) | rep; // eq <= 4096 windows of a tile
                 if (rep) atomicOr(&flagbits[p >> 5], 1u << (p & 31));
             }
         }
@@ -449,8 +446,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
         const u32 e = (eidx[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
         if (e != 0xffffu) {
             const u32 r = queue[e];
-            pr[i] = ((r & 0xfffu) << 1) | ((r >> 12) & 1u);
-            ab[i] = r >> 13;
+            pa[i] = ((r >> 13) << 16) | ((r & 0xfffu) << 1) | ((r >> 12) & 1u);
         }
     }
     __syncthreads();
@@ -474,10 +470,10 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     auto stage_reps = [&]() { // representatives -> LDS in distinct-rank order (tmp is free after phase 5)
 #pragma unroll
         for (int i = 0; i < SK_E; i++) {
-            if (pr[i] != 0xffffffffu && (pr[i] & 1u)) {
-                const u32 d = drank(pr[i] >> 1);
+            if (pa[i] & 1u) {
+                const u32 d = drank((pa[i] >> 1) & 0xfffu);
                 tmp[d] = h[i];
-                abund_s[d] = (u16)ab[i];
+                abund_s[d] = (u16)(pa[i] >> 16);
             }
         }
     };
@@ -590,8 +586,8 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < SK_E; i++)
-                if (pr[i] != 0xffffffffu && (pr[i] & 1u))
-                    ab[i] = atomicAdd(&bins[ks_join_prefix(h[i], A.part_K) & A.part_mask], 1u); // rank inside (tile, digit)
+                if (pa[i] & 1u) // rank inside (tile, digit) replaces the abundance (already staged)
+                    pa[i] = (pa[i] & 0xffffu) | (atomicAdd(&bins[ks_join_prefix(h[i], A.part_K) & A.part_mask], 1u) << 16);
             __syncthreads();
             {
                 const u32 c = tid < 256 ? bins[tid] : 0;
@@ -610,8 +606,8 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < SK_E; i++)
-                if (pr[i] != 0xffffffffu && (pr[i] & 1u)) {
-                    const u32 pos = bins[ks_join_prefix(h[i], A.part_K) & A.part_mask] + ab[i];
+                if (pa[i] & 1u) {
+                    const u32 pos = bins[ks_join_prefix(h[i], A.part_K) & A.part_mask] + (pa[i] >> 16);
                     tmp[pos] = h[i];
                     qrel[pos] = (u16)SK_BO_S(bo[i]);
                 }
