@@ -208,6 +208,17 @@ uint64_t ks_hits_n_pair_instances(const ks_hits *h); /* Σ_h q(h)·t(h): matched
 int ks_hits_partition_path(const ks_hits *h);
 int ks_hits_copy_to_host(ks_ctx *ctx, const ks_hits *h, uint32_t *qid, uint32_t *tid,
                          uint32_t *intersect, uint64_t *n_weighted);
+/* Device-resident COO columns (valid until ks_hits_free; ks_hits_count entries each) — what a multi-GPU caller hands to
+ * RCCL without a host round trip (hit lists of shards are disjoint and only concatenated). */
+const uint32_t *ks_hits_device_qid(const ks_hits *h);
+const uint32_t *ks_hits_device_tid(const ks_hits *h);
+const uint32_t *ks_hits_device_intersect(const ks_hits *h);
+const uint64_t *ks_hits_device_n_weighted(const ks_hits *h);
+/* Device-to-device copy of the columns into caller-owned device buffers (e.g. the send block of an all-gather), with
+ * qid_base / tid_base added to the ids (a shard's local numbering -> global).  Asynchronous on ctx's stream; any
+ * destination may be NULL. */
+int ks_hits_copy_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qid_base, uint32_t tid_base, uint32_t *d_qid,
+                           uint32_t *d_tid, uint32_t *d_intersect, uint64_t *d_n_weighted);
 void ks_hits_free(ks_hits *h);
 
 /* ---- measurement --------------------------------------------------------------------------- */

@@ -51,7 +51,7 @@ int ksh_index_load(const char *path, int device, ksh_index **out, char *err, siz
 void ksh_string_free(char *s);
 
 /* ---- pipelined FASTA ingest (kmerseek_amd/csrc/ks_ingest.cpp) -------------------------------------
- * FASTA file (plain or gzip) -> the sketches of all its records as one host CSR, with the stages running concurrently:
+ * FASTA file (plain, gzip or zstd) -> the sketches of all its records as one host CSR, with the stages running concurrently:
  * reader thread -> validate / pack threads into pinned buffers -> H2D on a copy stream -> ks_sketch_batch_device + D2H.
  *   validate = 1: upper-case + AminoAcidAmbiguity::validate_and_resolve per record, first bad residue aborts with the
  *                 reference's message (the Rust index path: src/rust/index.rs:984-1016, aminoacid.rs:74-105);
@@ -69,6 +69,14 @@ const char *ksh_fs_names(ksh_fasta_sketches *r, uint64_t *len); /* record ids jo
 /* seconds[6] = wall, reader busy, validate/pack busy, H2D busy, device (sketch + D2H to pinned) busy, collector busy */
 void ksh_fs_stats(const ksh_fasta_sketches *r, uint64_t *n_residues, uint64_t *n_windows, uint64_t *n_batches, double *seconds);
 void ksh_fs_free(ksh_fasta_sketches *r);
+
+/* ---- input layer on its own (kmerseek_amd/csrc/ks_input.cpp): plain / gzip / zstd by magic number, as needletail's
+ * parse_fastx_file does for the reference (src/rust/index.rs:907-961, tested at :1734-1845).  Whole file decompressed into
+ * a malloc'ed buffer (ksh_input_free); format = "plain" | "gzip" | "zstd".  A truncated archive is an error (11), never a
+ * shorter file.  Needs no GPU. */
+int ksh_input_decompress(const char *path, uint8_t **data, uint64_t *len, char *format, uint32_t format_cap, char *err,
+                         uint32_t err_cap);
+void ksh_input_free(uint8_t *data);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,11 @@ SIGNATURES = {
     "ks_hits_n_pair_instances": (C.c_uint64, [_vp]),
     "ks_hits_partition_path": (C.c_int, [_vp]),
     "ks_hits_copy_to_host": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "ks_hits_device_qid": (_vp, [_vp]),
+    "ks_hits_device_tid": (_vp, [_vp]),
+    "ks_hits_device_intersect": (_vp, [_vp]),
+    "ks_hits_device_n_weighted": (_vp, [_vp]),
+    "ks_hits_copy_to_device": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "ks_hits_free": (None, [_vp]),
     "ks_timing_enable": (C.c_int, [_vp, C.c_int]),
     "ks_timing_reset": (C.c_int, [_vp]),

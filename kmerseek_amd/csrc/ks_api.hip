@@ -90,10 +90,18 @@ extern "C" int ks_sketches_from_host(ks_ctx *ctx, const uint64_t *offsets, const
     if (offsets[0] != 0) return ks_fail(ctx, KS_ERR_INVALID_ARG, "offsets[0] must be 0");
     const u64 n = offsets[n_seqs];
     if (n && (!hashes || !abunds)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "hashes/abunds is NULL");
+    // the index / join arithmetic assumes 0 < h <= max_hash(scaled) (ks_join_prefix < 2^pbits, sort prefix < 2^S): a
+    // sketch made with a smaller `scaled` than the one passed here would wrap into foreign buckets and lose matches silently
+    const u64 max_hash = ks_max_hash(params->scaled);
     for (u32 s = 0; s < n_seqs; s++) {
         if (offsets[s + 1] < offsets[s]) return ks_fail(ctx, KS_ERR_INVALID_ARG, "offsets must be ascending");
-        for (u64 j = offsets[s] + 1; j < offsets[s + 1]; j++)
-            if (hashes[j] <= hashes[j - 1]) return ks_fail(ctx, KS_ERR_INVALID_ARG, "sketch %u is not strictly ascending", s);
+        for (u64 j = offsets[s]; j < offsets[s + 1]; j++) {
+            if (hashes[j] == 0 || hashes[j] > max_hash)
+                return ks_fail(ctx, KS_ERR_INVALID_ARG, "sketch %u holds hash %llu outside (0, max_hash(scaled=%u)]", s,
+                               (unsigned long long)hashes[j], params->scaled);
+            if (j > offsets[s] && hashes[j] <= hashes[j - 1])
+                return ks_fail(ctx, KS_ERR_INVALID_ARG, "sketch %u is not strictly ascending", s);
+        }
     }
     KS_HIP(ctx, hipSetDevice(ctx->device));
     ks_sketches *S = new ks_sketches();
@@ -240,6 +248,30 @@ extern "C" int ks_hits_copy_to_host(ks_ctx *ctx, const ks_hits *h, uint32_t *qid
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
 }
+extern "C" const uint32_t *ks_hits_device_qid(const ks_hits *h) { return h ? h->d_qid : nullptr; }
+extern "C" const uint32_t *ks_hits_device_tid(const ks_hits *h) { return h ? h->d_tid : nullptr; }
+extern "C" const uint32_t *ks_hits_device_intersect(const ks_hits *h) { return h ? h->d_isect : nullptr; }
+extern "C" const uint64_t *ks_hits_device_n_weighted(const ks_hits *h) { return h ? h->d_nw : nullptr; }
+
+__global__ __launch_bounds__(256) void k_copy_add_u32(const u32 *in, u32 *out, u64 n, u32 add) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + add;
+}
+
+extern "C" int ks_hits_copy_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qid_base, uint32_t tid_base, uint32_t *d_qid,
+                                      uint32_t *d_tid, uint32_t *d_intersect, uint64_t *d_n_weighted) {
+    if (!ctx || !h) return KS_ERR_INVALID_ARG;
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    const u64 n = h->n_hits;
+    if (n == 0) return KS_OK;
+    const u32 g = (u32)((n + 255) / 256);
+    if (d_qid) KS_LAUNCH(ctx, "hits_copy", k_copy_add_u32, g, 256, (const u32 *)h->d_qid, d_qid, n, qid_base);
+    if (d_tid) KS_LAUNCH(ctx, "hits_copy", k_copy_add_u32, g, 256, (const u32 *)h->d_tid, d_tid, n, tid_base);
+    if (d_intersect) KS_HIP(ctx, hipMemcpyAsync(d_intersect, h->d_isect, (size_t)n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+    if (d_n_weighted) KS_HIP(ctx, hipMemcpyAsync(d_n_weighted, h->d_nw, (size_t)n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+    return KS_OK;
+}
+
 extern "C" void ks_hits_free(ks_hits *h) {
     if (!h) return;
     ks_pool_free(h->ctx, h->d_qid);

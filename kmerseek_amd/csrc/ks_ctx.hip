@@ -385,16 +385,20 @@ static inline u64 splitmix64(u64 *s) {
 extern "C" int ks_validate_and_resolve(const uint8_t *seq, uint64_t len, int upper, uint64_t rng_seed,
                                        uint8_t *out, uint64_t *out_len, ks_residue_error *err) {
     if ((!seq && len) || !out || !out_len) return KS_ERR_INVALID_ARG;
-    // class LUT: 0 invalid, 1 plain valid (20 standard + X U O), 2 stop, 3/4/5 = B/Z/J
-    static u8 cls[256];
-    static bool init = false;
-    if (!init) {
-        memset(cls, 0, sizeof cls);
-        for (const char *p = "ACDEFGHIKLMNPQRSTVWYXUO"; *p; p++) cls[(u8)*p] = 1; // aminoacid.rs:8-14
-        cls[(u8)'*'] = 2;
-        cls[(u8)'B'] = 3; cls[(u8)'Z'] = 4; cls[(u8)'J'] = 5; // aminoacid.rs:32-36
-        init = true;
-    }
+    // class LUT: 0 invalid, 1 plain valid (20 standard + X U O), 2 stop, 3/4/5 = B/Z/J.  Called from many packer threads
+    // at once (ks_ingest.cpp, ks_host.cpp): the table is a function-local static built by its initialiser (C++11
+    // guarantees one thread runs it and the others wait), and never written afterwards.
+    struct cls_table {
+        u8 v[256];
+        cls_table() {
+            memset(v, 0, sizeof v);
+            for (const char *p = "ACDEFGHIKLMNPQRSTVWYXUO"; *p; p++) v[(u8)*p] = 1; // aminoacid.rs:8-14
+            v[(u8)'*'] = 2;
+            v[(u8)'B'] = 3; v[(u8)'Z'] = 4; v[(u8)'J'] = 5; // aminoacid.rs:32-36
+        }
+    };
+    static const cls_table cls_tab;
+    const u8 *cls = cls_tab.v;
     u64 n = 0, rng = rng_seed, bits = 0;
     int nbits = 0;
     for (u64 i = 0; i < len; i++) {

@@ -3,17 +3,18 @@
 // the HIP library through ks_sketch_batch / ks_kmer_positions / ks_sketches_union.
 #include "../../include/kmerseek_host.hpp"
 
-#include <zlib.h>
 
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include <thread>
 
 #include "../../include/kmerseek_amd.h"
 #include "../../include/kmerseek_host_c.h"
+#include "ks_input.h"
 
 namespace kmerseek {
 
@@ -267,25 +268,15 @@ void ProteomeIndex::store_signatures_batch(const std::vector<ProteinSignature> &
 
 void ProteomeIndex::process_fasta(const std::string &fasta_path, uint32_t progress_interval, size_t batch_size) {
     if (progress_interval > 0) printf("Reading FASTA file with automatic compression detection and parallel processing...\n");
-    {   // zlib reads plain and gzip transparently; other magic numbers are what niffler would have handled
-        FILE *f = fopen(fasta_path.c_str(), "rb");
-        if (!f) throw IndexError(IndexError::ParseError, "Parse error: cannot open " + fasta_path + ": " + strerror(errno));
-        unsigned char m[6] = {0};
-        size_t got = fread(m, 1, 6, f);
-        fclose(f);
-        if (got >= 4 && ((m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd) || (m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') ||
-                         (m[0] == 0xfd && m[1] == '7' && m[2] == 'z' && m[3] == 'X')))
-            throw IndexError(IndexError::ParseError, "Parse error: zstd / bzip2 / xz input is not supported by this build (plain or gzip only): " + fasta_path);
-    }
-    gzFile gz = gzopen(fasta_path.c_str(), "rb");
-    if (!gz) throw IndexError(IndexError::ParseError, "Parse error: cannot open " + fasta_path);
-    gzbuffer(gz, 1 << 20);
+    // plain / gzip / zstd by magic number (ks_input.h), as needletail's parse_fastx_file does (index.rs:907-961)
+    std::string oerr;
+    std::unique_ptr<KsInput> in(KsInput::open(fasta_path.c_str(), oerr));
+    if (!in) throw IndexError(IndexError::ParseError, "Parse error: " + oerr);
     if (batch_size == 0) batch_size = 1000;
     std::vector<std::pair<std::string, std::string>> batch; // (sequence, id)
     size_t record_count = 0;
     std::string line, id, seq;
     bool have = false;
-    std::vector<char> buf(1 << 16);
     auto flush_record = [&]() {
         if (!have) return;
         batch.emplace_back(std::move(seq), std::move(id));
@@ -297,33 +288,37 @@ void ProteomeIndex::process_fasta(const std::string &fasta_path, uint32_t progre
         }
         if (progress_interval > 0 && record_count % progress_interval == 0) printf("Read %zu sequences...\n", record_count);
     };
-    try {
-        while (gzgets(gz, buf.data(), (int)buf.size())) {
-            line.assign(buf.data());
-            bool eol = !line.empty() && line.back() == '\n';
-            while (!eol && gzgets(gz, buf.data(), (int)buf.size())) { // long lines
-                line += buf.data();
-                eol = !line.empty() && line.back() == '\n';
-            }
-            while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
-            if (line.empty()) continue;
-            if (line[0] == '>') {
-                flush_record();
-                id = line.substr(1);
-                have = true;
-            } else if (have) {
-                seq += line;
-            } else {
-                throw IndexError(IndexError::ParseError, "Parse error: FASTA record does not start with '>'");
-            }
+    auto take_line = [&]() { // `line` holds one line without its terminator
+        while (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) return;
+        if (line[0] == '>') {
+            flush_record();
+            id = line.substr(1);
+            have = true;
+        } else if (have) {
+            seq += line;
+        } else {
+            throw IndexError(IndexError::ParseError, "Parse error: FASTA record does not start with '>'");
         }
-        flush_record();
-        if (!batch.empty()) store_signatures(create_protein_signatures(batch, true));
-    } catch (...) {
-        gzclose(gz);
-        throw;
+    };
+    std::vector<char> buf(1 << 20);
+    for (;;) {
+        const long n = in->read(buf.data(), buf.size());
+        if (n < 0) throw IndexError(IndexError::ParseError, "Parse error: " + in->error());
+        if (n == 0) break;
+        const char *p = buf.data(), *end = p + n;
+        while (p < end) {
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            if (!nl) { line.append(p, (size_t)(end - p)); break; } // the line goes on in the next chunk
+            line.append(p, (size_t)(nl - p));
+            take_line();
+            line.clear();
+            p = nl + 1;
+        }
     }
-    gzclose(gz);
+    if (!line.empty()) { take_line(); line.clear(); } // last line without a terminator
+    flush_record();
+    if (!batch.empty()) store_signatures(create_protein_signatures(batch, true));
     save_state();
     if (progress_interval > 0) printf("Successfully processed and stored %zu sequences.\n", record_count);
 }
@@ -331,8 +326,6 @@ void ProteomeIndex::process_fasta(const std::string &fasta_path, uint32_t progre
 // ---- persistence: flat little-endian file (own format; RocksDB layout is out of scope) --------------------
 static void put_u64(std::ostream &o, uint64_t v) { o.write((const char *)&v, 8); }
 static void put_str(std::ostream &o, const std::string &s) { put_u64(o, s.size()); o.write(s.data(), (std::streamsize)s.size()); }
-static uint64_t get_u64(std::istream &i) { uint64_t v = 0; i.read((char *)&v, 8); return v; }
-static std::string get_str(std::istream &i) { uint64_t n = get_u64(i); std::string s(n, '\0'); i.read(&s[0], (std::streamsize)n); return s; }
 
 void ProteomeIndex::save_state() {
     std::ofstream o(path_, std::ios::binary | std::ios::trunc);
@@ -364,46 +357,89 @@ void ProteomeIndex::save_state() {
     if (!o) throw IndexError(IndexError::Io, "IO error: short write to " + path_);
 }
 
+// Bounded reader of the flat index file: every length field is checked against the bytes that remain BEFORE anything is
+// allocated, and the stream state after every block, so a corrupt or foreign file that happens to start with the magic
+// fails with an IndexError instead of a multi-GB allocation.
+namespace {
+struct IndexReader {
+    std::istream &i;
+    uint64_t left;
+    const std::string &path;
+    [[noreturn]] void corrupt(const char *what) const {
+        throw IndexError(IndexError::Io, "IO error: corrupt index file " + path + " (" + what + ")");
+    }
+    void need(uint64_t n, const char *what) const { if (n > left) corrupt(what); }
+    void raw(void *dst, uint64_t n, const char *what) {
+        need(n, what);
+        i.read((char *)dst, (std::streamsize)n);
+        if (!i) corrupt(what);
+        left -= n;
+    }
+    uint64_t u64(const char *what) { uint64_t v = 0; raw(&v, 8, what); return v; }
+    // a count of records that each take at least `min_each` bytes of the file
+    uint64_t count(uint64_t min_each, const char *what) {
+        const uint64_t n = u64(what);
+        if (min_each && n > left / min_each) corrupt(what);
+        return n;
+    }
+    std::string str(const char *what) {
+        const uint64_t n = count(1, what);
+        std::string s((size_t)n, '\0');
+        if (n) raw(&s[0], n, what);
+        return s;
+    }
+};
+} // namespace
+
 std::unique_ptr<ProteomeIndex> ProteomeIndex::load(const std::string &path, int device) {
     std::ifstream i(path, std::ios::binary);
     char magic[8] = {0};
     if (!i || !i.read(magic, 8) || memcmp(magic, "KSIDX001", 8) != 0)
         throw IndexError(IndexError::NoSavedState, "No saved state found in database"); // errors.rs:23-24
-    std::string moltype = get_str(i);
-    uint32_t k = (uint32_t)get_u64(i), sc = (uint32_t)get_u64(i);
-    bool raw = get_u64(i) != 0;
+    i.seekg(0, std::ios::end);
+    const uint64_t size = (uint64_t)i.tellg();
+    i.seekg(8, std::ios::beg);
+    IndexReader r{i, size - 8, path};
+    std::string moltype = r.str("moltype");
+    const uint64_t k64 = r.u64("ksize"), sc64 = r.u64("scaled");
+    if (k64 == 0 || k64 > 0xffffffffULL || sc64 == 0 || sc64 > 0xffffffffULL) r.corrupt("ksize / scaled");
+    const uint32_t k = (uint32_t)k64, sc = (uint32_t)sc64;
+    const bool raw = r.u64("store_raw") != 0;
+    uint32_t mt_id = 0;
+    if (ks_moltype_from_string(moltype.c_str(), &mt_id) != KS_OK || k > KS_MAX_KSIZE) r.corrupt("moltype / ksize");
     auto ix = std::make_unique<ProteomeIndex>(path, k, sc, moltype, raw, device);
-    uint64_t nc = get_u64(i);
+    const uint64_t nc = r.count(16, "combined sketch size");
     ix->combined_mins_.resize(nc); ix->combined_abunds_.resize(nc);
-    i.read((char *)ix->combined_mins_.data(), (std::streamsize)(nc * 8));
-    i.read((char *)ix->combined_abunds_.data(), (std::streamsize)(nc * 8));
-    uint64_t ns = get_u64(i);
+    r.raw(ix->combined_mins_.data(), nc * 8, "combined mins");
+    r.raw(ix->combined_abunds_.data(), nc * 8, "combined abundances");
+    const uint64_t ns = r.count(40, "signature count"); // name + md5 + mins + raw flag + k-mer count: >= 5 length words
     for (uint64_t s = 0; s < ns; s++) {
         ProteinSignature g;
-        g.name = get_str(i); g.md5sum = get_str(i);
+        g.name = r.str("name"); g.md5sum = r.str("md5sum");
         g.moltype = moltype; g.protein_ksize = k; g.scaled = sc;
-        uint64_t nm = get_u64(i);
+        const uint64_t nm = r.count(16, "mins size");
         g.mins.resize(nm); g.abunds.resize(nm);
-        i.read((char *)g.mins.data(), (std::streamsize)(nm * 8));
-        i.read((char *)g.abunds.data(), (std::streamsize)(nm * 8));
-        if (get_u64(i)) g.raw_sequence = get_str(i);
-        uint64_t nk = get_u64(i);
+        r.raw(g.mins.data(), nm * 8, "mins");
+        r.raw(g.abunds.data(), nm * 8, "abundances");
+        if (r.u64("raw flag")) g.raw_sequence = r.str("raw sequence");
+        const uint64_t nk = r.count(24, "k-mer count");
         for (uint64_t q = 0; q < nk; q++) {
-            uint64_t h = get_u64(i);
+            const uint64_t h = r.u64("k-mer hash");
             KmerInfo &ki = g.kmer_infos[h];
-            ki.ksize = k; ki.hashval = h; ki.encoded_kmer = get_str(i);
-            uint64_t no = get_u64(i);
+            ki.ksize = k; ki.hashval = h; ki.encoded_kmer = r.str("encoded k-mer");
+            const uint64_t no = r.count(16, "original k-mer count");
             for (uint64_t o = 0; o < no; o++) {
-                std::string orig = get_str(i);
-                uint64_t np = get_u64(i);
+                std::string orig = r.str("original k-mer");
+                const uint64_t np = r.count(8, "position count");
                 auto &v = ki.original_kmer_to_position[orig];
-                for (uint64_t x = 0; x < np; x++) v.push_back((size_t)get_u64(i));
+                v.reserve((size_t)np);
+                for (uint64_t x = 0; x < np; x++) v.push_back((size_t)r.u64("position"));
             }
         }
         std::string key = g.md5sum;
         ix->signatures_[key] = std::move(g);
     }
-    if (!i) throw IndexError(IndexError::Io, "IO error: truncated index file " + path);
+    if (r.left != 0) r.corrupt("trailing bytes");
     return ix;
 }
 

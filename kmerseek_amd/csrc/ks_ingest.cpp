@@ -4,7 +4,7 @@
 // runs them through rayon and only then reads on.  At GPU sketching rates the parser and the PCIe copies are the
 // whole cost, so here the stages run concurrently, each in its own thread, connected by bounded queues:
 //
-//   reader    plain / gzip FASTA -> raw record batches of >= batch_residues residues
+//   reader    plain / gzip / zstd FASTA (ks_input.h) -> raw record batches of >= batch_residues residues
 //   packer    validate_and_resolve (aminoacid.rs:74-105; upper-cased first as index.rs:1000 does) on host threads, or
 //             raw record bytes as manysketch takes them (sketch.py:28-40) -> residues + offsets in a PINNED slot
 //   uploader  hipMemcpyAsync of the slot on its own stream (overlaps the kernels of the previous batch)
@@ -15,7 +15,6 @@
 // `pipeline = 0` runs the same five steps one after the other in the calling thread (the baseline the overlap is
 // measured against).  Nothing here computes a hash on the CPU.
 #include <hip/hip_runtime.h>
-#include <zlib.h>
 
 #include <atomic>
 #include <chrono>
@@ -23,6 +22,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -30,6 +30,7 @@
 
 #include "../../include/kmerseek_amd.h"
 #include "../../include/kmerseek_host_c.h"
+#include "ks_input.h"
 
 namespace {
 
@@ -163,15 +164,17 @@ class Ingest {
             err = "hipStreamCreate failed";
             return 13;
         }
-        gz_ = gzopen(path_.c_str(), "rb");
-        if (!gz_) { err = "Parse error: cannot open " + path_; return 11; }
-        gzbuffer(gz_, 1 << 20);
+        {
+            std::string oerr;
+            in_.reset(KsInput::open(path_.c_str(), oerr));
+            if (!in_) { err = "Parse error: " + oerr; return 11; }
+        }
         slots_.resize(pipeline_ ? 3 : 1);
         if (!out_->offsets.reserve_more(1)) { err = "out of host memory"; return 13; }
         out_->offsets.p[0] = 0;
         out_->offsets.n = 1;
         if (pipeline_) run_pipelined(); else run_serial();
-        gzclose(gz_);
+        in_.reset();
         out_->t_wall = secs(t0, clk::now());
         if (fail_.set.load()) { err = fail_.msg; return fail_.code; }
         return 0;
@@ -179,7 +182,7 @@ class Ingest {
 
   private:
     // ---- stage 1: reader ------------------------------------------------------------------------------------------
-    // Bulk gzread + memchr over 4 MiB chunks; sequence bytes go straight into the batch's contiguous buffer (no
+    // Bulk read + memchr over 4 MiB chunks; sequence bytes go straight into the batch's contiguous buffer (no
     // per-line or per-record strings: the line-by-line reader this replaced parsed 0.4 GB/s and WAS the pipeline).
     bool read_batch(RawBatch &b) { // false at end of file with nothing read
         const auto t0 = clk::now();
@@ -190,8 +193,8 @@ class Ingest {
         while (!cut && !fail_.set.load()) {
             if (pos_ == len_) {
                 if (eof_) break;
-                const int n = gzread(gz_, chunk_.data(), (unsigned)chunk_.size());
-                if (n < 0) { fail_.raise(11, "Parse error: read failed (truncated or corrupt input?)"); break; }
+                const long n = in_->read(chunk_.data(), chunk_.size());
+                if (n < 0) { fail_.raise(11, "Parse error: " + in_->error()); break; }
                 if (n == 0) { eof_ = true; break; }
                 pos_ = 0;
                 len_ = (size_t)n;
@@ -487,7 +490,7 @@ class Ingest {
     ks_params params_{};
     ks_ctx *ctx_ = nullptr;
     hipStream_t copy_stream_ = nullptr;
-    gzFile gz_ = nullptr;
+    std::unique_ptr<KsInput> in_;
     enum LineKind { LINE_START, HEADER, SEQ };
     std::vector<uint8_t> chunk_ = std::vector<uint8_t>(4u << 20);
     size_t pos_ = 0, len_ = 0;

@@ -11,7 +11,8 @@ Two ways to shard a search, both without any data-path collective inside the hot
   per-pair sum across ranks — a reduce-by-key over the network — and is rejected.)
 
 Either way the only exchange is the concatenation of variable-length COO hit lists: a count all-gather
-followed by one padded all-gather (``all_gather_hits``).
+followed by one padded all-gather of device-resident blocks (``all_gather_hits_device``: the shard's hit columns go D2D
+from the ``ks_hits`` object into the send block, no host staging, no host sort).
 """
 from __future__ import annotations
 
@@ -79,37 +80,67 @@ def broadcast_batch(residues: Optional[np.ndarray], offsets: Optional[np.ndarray
     return t_res, t_off
 
 
-def all_gather_hits(hits: Hits, qid_base: int = 0, tid_base: int = 0, device=None) -> Hits:
-    """Concatenate every rank's COO hit list (ids shifted to global numbering) and return it sorted by
-    (qid, tid) on every rank.  Counts are exchanged first, then one padded all-gather moves the rows."""
+def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=None, sharded: str = "queries"):
+    """Concatenate every rank's COO hit list on the device: counts are exchanged first, then ONE padded
+    ``all_gather_into_tensor`` moves the rows (RCCL over xGMI with backend "nccl"; gloo on CPU tensors in the tests).
+
+    hits    : a device-resident ``engine.Hits`` — its columns go D2D straight into the send block
+              (``ks_hits_copy_to_device``, ids shifted to global numbering by the copy kernel; no host round trip) —
+              or a numpy 4-tuple of host columns (CPU tensors / gloo).
+    sharded : "queries" — ranks own ascending qid ranges, so the concatenation in rank order already IS (qid, tid) order;
+              "index"   — ranks own ascending tid ranges: one stable device sort on qid restores (qid, tid) order.
+    Returns (qid i32, tid i32, intersect i32, n_weighted i64) torch tensors on `device`, identical on every rank."""
     import torch
     dist = _dist()
     rank, world = world_info()
-    qid, tid, isect, nw = hits
-    qid = qid.astype(np.int64) + qid_base
-    tid = tid.astype(np.int64) + tid_base
-    if world == 1:
-        rows = np.stack([qid, tid, isect.astype(np.int64), nw.astype(np.int64)], axis=1) if len(qid) else \
-            np.zeros((0, 4), np.int64)
+    dev = device if device is not None else torch.device("cpu")
+    on_device = hasattr(hits, "copy_to_device")
+    if on_device and dev.type != "cuda":  # collective buffers on the host (gloo rehearsal): the columns have to come down
+        hits, on_device = hits.to_host(), False
+    n_local = int(hits.count) if on_device else len(hits[0])
+    counts = [n_local]
+    if world > 1:
+        mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        allc = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allc, mine)
+        counts = [int(c) for c in allc.tolist()]
+    cap = (max(max(counts), 1) + 63) // 64 * 64  # even: the i64 column of a block stays 8-byte aligned
+    # one block per rank, SoA: qid[cap] | tid[cap] | intersect[cap] | n_weighted[cap] (as 2 x i32 each)
+    send = torch.empty(5 * cap, dtype=torch.int32, device=dev)
+    if n_local:
+        if on_device:
+            base = send.data_ptr()
+            hits.copy_to_device(base, base + 4 * cap, base + 8 * cap, base + 12 * cap, qid_base=qid_base, tid_base=tid_base)
+            if hits._ctx.stream != torch.cuda.current_stream(dev).cuda_stream:
+                hits._ctx.synchronize()  # the copy ran on the context's own stream; the collective runs on torch's
+        else:
+            qid, tid, isect, nw = hits
+            send[0:n_local] = torch.from_numpy((qid.astype(np.int64) + qid_base).astype(np.int32)).to(dev)
+            send[cap:cap + n_local] = torch.from_numpy((tid.astype(np.int64) + tid_base).astype(np.int32)).to(dev)
+            send[2 * cap:2 * cap + n_local] = torch.from_numpy(isect.astype(np.int32)).to(dev)
+            send[3 * cap:5 * cap].view(torch.int64)[:n_local] = torch.from_numpy(nw.astype(np.int64)).to(dev)
+    if world > 1:
+        recv = torch.empty(world * 5 * cap, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(recv, send)
     else:
-        dev = device if device is not None else torch.device("cpu")
-        n_local = torch.tensor([len(qid)], dtype=torch.int64, device=dev)
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(counts, n_local)
-        counts = [int(c[0]) for c in counts]
-        cap = max(max(counts), 1)
-        local = torch.zeros((cap, 4), dtype=torch.int64, device=dev)
-        if len(qid):
-            local[:len(qid)] = torch.from_numpy(
-                np.stack([qid, tid, isect.astype(np.int64), nw.astype(np.int64)], axis=1)).to(dev)
-        gathered = [torch.zeros((cap, 4), dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(gathered, local)
-        rows = np.concatenate([g[:c].cpu().numpy() for g, c in zip(gathered, counts)], axis=0)
-    if len(rows):
-        order = np.lexsort((rows[:, 1], rows[:, 0]))
-        rows = rows[order]
-    return (rows[:, 0].astype(np.uint32), rows[:, 1].astype(np.uint32), rows[:, 2].astype(np.uint32),
-            rows[:, 3].astype(np.uint64))
+        recv = send
+    cols = [[], [], [], []]
+    for r, c in enumerate(counts):
+        blk = recv[r * 5 * cap:(r + 1) * 5 * cap]
+        cols[0].append(blk[0:c]); cols[1].append(blk[cap:cap + c]); cols[2].append(blk[2 * cap:2 * cap + c])
+        cols[3].append(blk[3 * cap:5 * cap].view(torch.int64)[:c])
+    qid, tid, isect, nw = (torch.cat(c) for c in cols)
+    if sharded == "index" and world > 1 and qid.numel():
+        order = torch.sort(qid, stable=True).indices  # inside one qid, rank order already is tid order
+        qid, tid, isect, nw = qid[order], tid[order], isect[order], nw[order]
+    return qid, tid, isect, nw
+
+
+def all_gather_hits(hits, qid_base: int = 0, tid_base: int = 0, device=None, sharded: str = "queries") -> Hits:
+    """``all_gather_hits_device`` with the result copied to host numpy arrays (qid u32, tid u32, intersect u32, n_weighted u64)."""
+    qid, tid, isect, nw = all_gather_hits_device(hits, qid_base, tid_base, device, sharded)
+    return (qid.cpu().numpy().view(np.uint32), tid.cpu().numpy().view(np.uint32), isect.cpu().numpy().view(np.uint32),
+            nw.cpu().numpy().view(np.uint64))
 
 
 SearchFn = Callable[[np.ndarray, np.ndarray, np.ndarray, np.ndarray], Hits]
@@ -122,7 +153,7 @@ def search_queries_sharded(search_fn: SearchFn, q_res: np.ndarray, q_off: np.nda
     rank, world = world_info()
     s0, s1 = shard_by_residues(q_off, world)[rank]
     lq_res, lq_off = slice_batch(q_res, q_off, s0, s1)
-    return all_gather_hits(search_fn(lq_res, lq_off, t_res, t_off), qid_base=s0, device=device)
+    return all_gather_hits(search_fn(lq_res, lq_off, t_res, t_off), qid_base=s0, device=device, sharded="queries")
 
 
 def search_index_sharded(search_fn: SearchFn, q_res: np.ndarray, q_off: np.ndarray, t_res: np.ndarray,
@@ -132,7 +163,7 @@ def search_index_sharded(search_fn: SearchFn, q_res: np.ndarray, q_off: np.ndarr
     rank, world = world_info()
     s0, s1 = shard_by_residues(t_off, world)[rank]
     lt_res, lt_off = slice_batch(t_res, t_off, s0, s1)
-    return all_gather_hits(search_fn(q_res, q_off, lt_res, lt_off), tid_base=s0, device=device)
+    return all_gather_hits(search_fn(q_res, q_off, lt_res, lt_off), tid_base=s0, device=device, sharded="index")
 
 
 def gpu_search_fn(ctx, ksize: int, scaled: int, moltype: str) -> SearchFn:
@@ -141,6 +172,5 @@ def gpu_search_fn(ctx, ksize: int, scaled: int, moltype: str) -> SearchFn:
         T = ctx.sketch_batch(t_res, t_off, ksize, scaled, moltype)
         Q = ctx.sketch_batch(q_res, q_off, ksize, scaled, moltype)
         ix = ctx.index_build(T)
-        hits = ctx.search(ix, Q).to_host()
-        return hits
+        return ctx.search(ix, Q)  # device-resident: all_gather_hits_device takes the columns D2D
     return fn

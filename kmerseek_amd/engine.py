@@ -339,6 +339,18 @@ class Hits(_Owned):
         """0 sketch regions == buckets, 1 regions + bucket scatter, 2 regions + dense pass, 3 dense from the CSR."""
         return int(self._ctx._L.ks_hits_partition_path(self._h))
 
+    def device_ptrs(self) -> Tuple[int, int, int, int]:
+        """Raw device pointers of the COO columns (qid u32, tid u32, intersect u32, n_weighted u64), `count` entries each."""
+        L = self._ctx._L
+        return tuple(int(f(self._h) or 0) for f in (L.ks_hits_device_qid, L.ks_hits_device_tid, L.ks_hits_device_intersect,
+                                                    L.ks_hits_device_n_weighted))
+
+    def copy_to_device(self, d_qid: int, d_tid: int, d_isect: int, d_nw: int, qid_base: int = 0, tid_base: int = 0):
+        """D2D copy of the columns into caller-owned device buffers (ids shifted to global numbering); asynchronous on the
+        context's stream.  This is how a shard's hits enter the send block of an all-gather (kmerseek_amd/dist.py)."""
+        self._ctx._check(self._ctx._L.ks_hits_copy_to_device(self._ctx._h, self._h, qid_base, tid_base, C.c_void_p(d_qid),
+                                                             C.c_void_p(d_tid), C.c_void_p(d_isect), C.c_void_p(d_nw)))
+
     def to_host(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
         n = self.count
         qid = np.zeros(n, np.uint32); tid = np.zeros(n, np.uint32)

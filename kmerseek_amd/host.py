@@ -52,6 +52,9 @@ HOST_SIGNATURES = {
     "ksh_fs_stats": (None, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                             C.POINTER(C.c_double)]),
     "ksh_fs_free": (None, [C.c_void_p]),
+    "ksh_input_decompress": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_char_p, C.c_uint32,
+                                       C.c_char_p, C.c_uint32]),
+    "ksh_input_free": (None, [C.c_void_p]),
 }
 
 _bound = None
@@ -92,6 +95,22 @@ def _take_string(L, p: C.c_void_p) -> str:
         return C.string_at(p).decode()
     finally:
         L.ksh_string_free(p)
+
+
+def decompress(path) -> tuple:
+    """-> (bytes, format) of a plain / gzip / zstd file through the ingest's input layer (ks_input.cpp): the
+    auto-detection needletail gives the reference (src/rust/index.rs:907-961).  Raises IndexError_ (ParseError) on a
+    truncated or corrupt archive.  Needs no GPU."""
+    L = _host()
+    data, n = C.c_void_p(), C.c_uint64()
+    fmt, err = C.create_string_buffer(16), C.create_string_buffer(_ERR_CAP)
+    rc = L.ksh_input_decompress(str(path).encode(), C.byref(data), C.byref(n), fmt, 16, err, _ERR_CAP)
+    if rc != 0:
+        raise IndexError_(rc, err.value.decode(errors="replace"))
+    try:
+        return C.string_at(data, n.value), fmt.value.decode()
+    finally:
+        L.ksh_input_free(data)
 
 
 def sum_as_string(a: int, b: int) -> str:

@@ -100,7 +100,14 @@ def read_sig_zip(path: str):
         mins.extend(sig["mins"])
         abunds.extend(sig.get("abundances") or [1] * len(sig["mins"]))
         offs.append(len(mins))
-        ksize, scaled, moltype = sig["ksize"] // 3, int(row["scaled"]), sig["molecule"]
+        have = (sig["ksize"] // 3, int(row["scaled"]), sig["molecule"])
+        if ksize is not None and have != (ksize, scaled, moltype):  # every row, not only the last one
+            raise ValueError(f"{path}: sketch {doc[0]['name']!r} was made with {have}, earlier ones with "
+                             f"{(ksize, scaled, moltype)}: one search takes one set of parameters")
+        ksize, scaled, moltype = have
+        mh = max_hash(scaled)
+        if any(h == 0 or h > mh for h in sig["mins"]) or (sig.get("max_hash") not in (None, 0, mh)):
+            raise ValueError(f"{path}: sketch {doc[0]['name']!r} holds hashes outside (0, max_hash(scaled={scaled})]")
     return (names, np.array(offs, np.uint64), np.array(mins, np.uint64), np.array(abunds, np.uint32), ksize, scaled,
             moltype)
 

@@ -220,6 +220,61 @@ size_t kso_kmer_positions(const uint8_t *seq, size_t len, uint32_t k, int moltyp
     return n;
 }
 
+/* Batch form of process_kmers for the CPU baseline: the second pass create_protein_signature makes over every
+ * record (src/rust/index.rs:737, 749-786) under the rayon loop of process_batch_parallel (:984-1016), with the
+ * reference's linear `contains` scan.  Returns the number of (start, hash) rows found; the rows are not kept. */
+typedef struct {
+    const uint8_t *residues; const uint64_t *seq_offsets; const uint64_t *sk_off; const uint64_t *sk_mins;
+    uint32_t s0, s1, k; int moltype; uint64_t seed; int faithful; uint64_t found;
+} kmerpos_job;
+
+static void *kmerpos_worker(void *arg) {
+    kmerpos_job *j = (kmerpos_job *)arg;
+    uint64_t max_len = 0;
+    for (uint32_t s = j->s0; s < j->s1; s++) {
+        uint64_t l = j->seq_offsets[s + 1] - j->seq_offsets[s];
+        if (l > max_len) max_len = l;
+    }
+    uint32_t *starts = (uint32_t *)malloc((max_len + 1) * sizeof(uint32_t));
+    uint64_t *hashes = (uint64_t *)malloc((max_len + 1) * sizeof(uint64_t));
+    for (uint32_t s = j->s0; s < j->s1; s++) {
+        uint64_t b = j->seq_offsets[s], e = j->seq_offsets[s + 1];
+        j->found += kso_kmer_positions(j->residues + b, (size_t)(e - b), j->k, j->moltype, j->seed,
+                                       j->sk_mins + j->sk_off[s], (size_t)(j->sk_off[s + 1] - j->sk_off[s]),
+                                       j->faithful, starts, hashes);
+    }
+    free(starts); free(hashes);
+    return NULL;
+}
+
+uint64_t kso_kmer_positions_batch(const uint8_t *residues, const uint64_t *seq_offsets, uint32_t n_seqs,
+                                  uint32_t k, int moltype, uint64_t seed, const uint64_t *sk_offsets,
+                                  const uint64_t *sk_mins, int faithful, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    if ((uint32_t)n_threads > n_seqs) n_threads = n_seqs ? (int)n_seqs : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    kmerpos_job *jobs = (kmerpos_job *)malloc(sizeof(kmerpos_job) * (size_t)n_threads);
+    uint64_t total_res = n_seqs ? seq_offsets[n_seqs] : 0;
+    uint32_t s = 0;
+    for (int t = 0; t < n_threads; t++) {
+        uint64_t target = total_res * (uint64_t)(t + 1) / (uint64_t)n_threads;
+        uint32_t s1 = s;
+        while (s1 < n_seqs && (seq_offsets[s1 + 1] <= target || t == n_threads - 1)) s1++;
+        if (t == n_threads - 1) s1 = n_seqs;
+        jobs[t] = (kmerpos_job){residues, seq_offsets, sk_offsets, sk_mins, s, s1, k, moltype, seed, faithful, 0};
+        s = s1;
+    }
+    if (n_threads == 1) kmerpos_worker(&jobs[0]);
+    else {
+        for (int t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, kmerpos_worker, &jobs[t]);
+        for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    }
+    uint64_t found = 0;
+    for (int t = 0; t < n_threads; t++) found += jobs[t].found;
+    free(th); free(jobs);
+    return found;
+}
+
 /* AminoAcidAmbiguity::validate_and_resolve, src/rust/aminoacid.rs:74-105. */
 int kso_validate_and_resolve(const uint8_t *seq, size_t len, const uint8_t *choices,
                              size_t n_choices, uint8_t *out, size_t *out_len, uint8_t *bad_char,

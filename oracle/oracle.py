@@ -54,6 +54,9 @@ def lib():
         L.kso_kmer_positions.restype = C.c_size_t
         L.kso_kmer_positions.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32, C.c_int, C.c_uint64,
                                          u64p, C.c_size_t, C.c_int, u32p, u64p]
+        L.kso_kmer_positions_batch.restype = C.c_uint64
+        L.kso_kmer_positions_batch.argtypes = [u8p, u64p, C.c_uint32, C.c_uint32, C.c_int, C.c_uint64, u64p, u64p,
+                                               C.c_int, C.c_int]
         L.kso_validate_and_resolve.restype = C.c_int
         L.kso_validate_and_resolve.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
                                                C.c_char_p, C.POINTER(C.c_size_t),
@@ -137,6 +140,23 @@ def kmer_positions(seq: bytes, ksize: int, moltype: str, mins: np.ndarray, seed:
     c = lib().kso_kmer_positions(seq, len(seq), ksize, moltype_id(moltype), seed, mp, mins.size,
                                  1 if faithful else 0, _p(starts, C.c_uint32), _p(hashes, C.c_uint64))
     return starts[:c].copy(), hashes[:c].copy()
+
+
+def kmer_positions_batch_count(residues: np.ndarray, offsets: np.ndarray, ksize: int, moltype: str, sk_offsets: np.ndarray,
+                               sk_mins: np.ndarray, seed: int = SEED, faithful: bool = True, n_threads: int = 1) -> int:
+    """process_kmers (src/rust/index.rs:749-786) over a whole batch, rows counted and dropped: bench.py's timing leg for
+    the second pass create_protein_signature makes.  faithful = the reference's linear `contains` scan."""
+    residues = np.ascontiguousarray(residues, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    sk_offsets = np.ascontiguousarray(sk_offsets, dtype=np.uint64)
+    sk_mins = np.ascontiguousarray(sk_mins, dtype=np.uint64)
+    if residues.size == 0:
+        residues = np.zeros(1, np.uint8)
+    if sk_mins.size == 0:
+        sk_mins = np.zeros(1, np.uint64)
+    return int(lib().kso_kmer_positions_batch(_p(residues, C.c_uint8), _p(offsets, C.c_uint64), len(offsets) - 1, ksize,
+                                              moltype_id(moltype), seed, _p(sk_offsets, C.c_uint64),
+                                              _p(sk_mins, C.c_uint64), 1 if faithful else 0, n_threads))
 
 
 def kmer_infos(seq: bytes, ksize: int, moltype: str, mins: np.ndarray) -> Dict[int, dict]:

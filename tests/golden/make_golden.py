@@ -237,7 +237,7 @@ def golden_search():
 
 
 def copy_inputs():
-    for rel in ("fasta/ced9.fasta", "fasta/" + BCL2, "fasta/test_compression.fasta"):
+    for rel in ("fasta/ced9.fasta", "fasta/" + BCL2, "fasta/test_compression.fasta", "fasta/test_compression.fasta.zst"):
         dst = os.path.join(OUT, os.path.basename(rel))
         shutil.copyfile(os.path.join(TD, rel), dst)
         os.chmod(dst, 0o644)

@@ -95,9 +95,14 @@ def test_shard_by_residues_balances_and_covers():
     assert r.tolist() == list(range(3, 10)) and o.tolist() == [0, 4, 7]
 
 
-def test_all_gather_hits_single_rank_sorts_and_shifts():
+def test_all_gather_hits_single_rank_shifts_ids():
+    # one rank: the (already (qid, tid)-ordered) local list comes back with its ids in global numbering
     from kmerseek_amd import dist as ksd
-    h = (np.array([1, 0, 1], np.uint32), np.array([5, 2, 1], np.uint32), np.array([3, 4, 5], np.uint32),
-         np.array([3, 4, 6], np.uint64))
+    h = (np.array([0, 1, 1], np.uint32), np.array([2, 1, 5], np.uint32), np.array([4, 5, 3], np.uint32),
+         np.array([4, 6, 3 + (1 << 40)], np.uint64))
     q, t, i, w = ksd.all_gather_hits(h, qid_base=10, tid_base=100)
-    assert q.tolist() == [10, 11, 11] and t.tolist() == [102, 101, 105] and i.tolist() == [4, 5, 3] and w.tolist() == [4, 6, 3]
+    assert q.tolist() == [10, 11, 11] and t.tolist() == [102, 101, 105] and i.tolist() == [4, 5, 3]
+    assert w.tolist() == [4, 6, 3 + (1 << 40)]
+    assert q.dtype == np.uint32 and w.dtype == np.uint64
+    e = (np.zeros(0, np.uint32),) * 3 + (np.zeros(0, np.uint64),)
+    assert all(len(x) == 0 for x in ksd.all_gather_hits(e))

@@ -3,6 +3,7 @@ the pairwise CPU search finishes in seconds, otherwise oracle on a query sample 
 (symmetry of all-vs-all, self hits, (qid, tid) order, N-shard == 1-shard)."""
 import numpy as np
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -95,8 +96,9 @@ def test_config5_all_vs_all_hp_k24_sharded(ctx):
     for s0, s1 in ksd.shard_by_residues(p[1], 8):
         sub = ksd.slice_batch(p[0], p[1], s0, s1)
         Ti = ctx.sketch_batch(sub[0], sub[1], k, scaled, mol)
-        h = ctx.search(ctx.index_build(Ti), S).to_host()
-        parts.append(ksd.all_gather_hits(h, tid_base=s0))
+        h = ctx.search(ctx.index_build(Ti), S)
+        # the device-resident exchange path (one rank here): columns D2D into the send block, ids shifted on the way
+        parts.append(ksd.all_gather_hits(h, tid_base=s0, device=torch.device("cuda", 0), sharded="index"))
     rows = np.concatenate([np.stack([x.astype(np.int64) for x in part], axis=1) for part in parts])
     rows = rows[np.lexsort((rows[:, 1], rows[:, 0]))]
     assert np.array_equal(rows[:, 0], qid) and np.array_equal(rows[:, 1], tid)
@@ -116,6 +118,18 @@ def test_dist_layer_single_rank_gpu(ctx):
     fn = ksd.gpu_search_fn(ctx, 10, 1, "protein")
     a = ksd.search_queries_sharded(fn, q[0], q[1], t[0], t[1])
     b = ksd.search_index_sharded(fn, q[0], q[1], t[0], t[1])
-    want = fn(q[0], q[1], t[0], t[1])
+    want = fn(q[0], q[1], t[0], t[1]).to_host()
+    assert len(want[0]) > 50
     for x, y, z in zip(a, b, want):
         assert np.array_equal(x, z) and np.array_equal(y, z)
+    # device-resident exchange: same rows without the columns ever visiting the host
+    dev = torch.device("cuda", 0)
+    h = fn(q[0], q[1], t[0], t[1])
+    got = ksd.all_gather_hits_device(h, qid_base=7, tid_base=9, device=dev)
+    assert all(g.device.type == "cuda" for g in got)
+    assert np.array_equal(got[0].cpu().numpy().view(np.uint32), want[0] + 7)
+    assert np.array_equal(got[1].cpu().numpy().view(np.uint32), want[1] + 9)
+    assert np.array_equal(got[2].cpu().numpy().view(np.uint32), want[2])
+    assert np.array_equal(got[3].cpu().numpy().view(np.uint64), want[3])
+    ptrs = h.device_ptrs()
+    assert all(p != 0 for p in ptrs)

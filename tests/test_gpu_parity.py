@@ -276,6 +276,16 @@ def test_sketches_from_host_roundtrip(ctx, golden_sketches, ced9_records):
     with pytest.raises(ks.KmerseekError):
         ctx.sketches_from_host(np.array([0, 2], np.uint64), np.array([5, 5], np.uint64), np.array([1, 1], np.uint32),
                                16, 5, "hp")
+    # hashes outside (0, max_hash(scaled)] — e.g. a sketch made with a smaller scaled — would wrap into foreign join
+    # buckets and lose matches silently: refused at the boundary
+    for bad in ([0, 7], [7, oracle.max_hash(5) + 1]):
+        with pytest.raises(ks.KmerseekError) as e:
+            ctx.sketches_from_host(np.array([0, 2], np.uint64), np.array(bad, np.uint64), np.array([1, 1], np.uint32),
+                                   16, 5, "hp")
+        assert "outside" in str(e.value)
+    ok = ctx.sketches_from_host(np.array([0, 2], np.uint64), np.array([7, oracle.max_hash(5)], np.uint64),
+                                np.array([1, 1], np.uint32), 16, 5, "hp")
+    assert ok.n_hashes == 2
 
 
 def test_full_size_properties(ctx):

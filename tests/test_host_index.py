@@ -332,3 +332,72 @@ def test_sketch_fasta_validate_path_and_errors(tmp_path):
     with pytest.raises(RuntimeError) as e:
         host.sketch_fasta(nohdr, 5, 1, "protein")
     assert "does not start with '>'" in str(e.value)
+
+
+# src/rust/index.rs:1734-1788 (test_process_fasta_zstd_moltype_protein) and :1790-1845 (gz): the same two records
+# through plain, gzip and zstd give the same index — 2 signatures, keys f7661cd829e75c0d / 7641839ad508ab8, union 24
+@pytest.mark.gpu
+def test_process_fasta_zstd_and_gz(tmp_path, index_kats):
+    case = index_kats["small_fasta"]["cases"][0]
+    assert (case["ksize"], case["scaled"], case["moltype"]) == (5, 1, "protein")
+    plain = os.path.join(GOLDEN, "test_compression.fasta")
+    gz = tmp_path / "test_compression.fasta.gz"
+    gz.write_bytes(gzip.compress(open(plain, "rb").read()))
+    made = {}
+    for tag, path in (("plain", plain), ("zst", os.path.join(GOLDEN, "test_compression.fasta.zst")), ("gz", str(gz))):
+        ix = new_index(tmp_path, 5, 1, "protein", name=f"fasta_{tag}_protein_test.db")
+        ix.process_fasta(path, 0, 1000)
+        sigs = ix.get_signatures()
+        assert len(sigs) == 2, tag
+        assert {k: len(v["kmer_infos"]) for k, v in sigs.items()} == {"f7661cd829e75c0d": 7, "7641839ad508ab8": 17}, tag
+        assert ix.combined_minhash_size() == 24, tag
+        made[tag] = ix
+    assert made["zst"].is_equivalent_to(made["plain"]) and made["gz"].is_equivalent_to(made["plain"])
+    # the pipelined ingest (manysketch path) reads all three the same way
+    ref = host.sketch_fasta(plain, 5, 1, "protein", validate=True)
+    for path in (os.path.join(GOLDEN, "test_compression.fasta.zst"), str(gz)):
+        got = host.sketch_fasta(path, 5, 1, "protein", validate=True)
+        assert got[0] == ref[0] and all(np.array_equal(x, y) for x, y in zip(got[1:4], ref[1:4]))
+    # a cut-off archive fails the whole file (no shorter proteome)
+    big = b"".join(b">r%d\n" % i + b"ACDEFGHIKLMNPQRSTVWY" * 50 + b"\n" for i in range(2000))
+    z = gzip.compress(big)
+    cut = tmp_path / "cut.fasta.gz"
+    cut.write_bytes(z[:len(z) // 2])
+    with pytest.raises(RuntimeError) as e:
+        host.sketch_fasta(cut, 5, 1, "protein", validate=True)
+    assert "truncated" in str(e.value)
+    ix = new_index(tmp_path, 5, 1, "protein", name="cut.db")
+    with pytest.raises(RuntimeError) as e:
+        ix.process_fasta(cut, 0, 1000)
+    assert "truncated" in str(e.value) and e.value.kind == "ParseError"
+
+
+# ProteomeIndex::load must not trust the length fields of the file
+@pytest.mark.gpu
+def test_load_rejects_truncated_and_garbage_files(tmp_path):
+    ix = new_index(tmp_path, 5, 1, "protein", raw=True, name="ok.db")
+    ix.add_records([("PLANTANDANIMALGENQMES", "p1"), ("LIVINGALIVE", "p2")])
+    ix.save_state()
+    blob = open(ix.path(), "rb").read()
+    assert host.ProteomeIndex.load(ix.path()).is_equivalent_to(ix)
+    for cut in (9, 20, len(blob) // 3, len(blob) // 2, len(blob) - 1):
+        p = tmp_path / f"cut{cut}.db"
+        p.write_bytes(blob[:cut])
+        with pytest.raises(RuntimeError) as e:
+            host.ProteomeIndex.load(str(p))
+        assert "corrupt index file" in str(e.value) and e.value.kind == "Io", cut
+    # a length field blown up to 2^60 must fail the bounds check, not allocate
+    import struct
+    for at in (8, 8 + 8 + len("protein") + 24):   # moltype length; combined-sketch size
+        bad = bytearray(blob)
+        bad[at:at + 8] = struct.pack("<Q", 1 << 60)
+        p = tmp_path / f"garbage{at}.db"
+        p.write_bytes(bytes(bad))
+        with pytest.raises(RuntimeError) as e:
+            host.ProteomeIndex.load(str(p))
+        assert "corrupt index file" in str(e.value), at
+    p = tmp_path / "trailing.db"
+    p.write_bytes(blob + b"\0" * 8)
+    with pytest.raises(RuntimeError) as e:
+        host.ProteomeIndex.load(str(p))
+    assert "corrupt index file" in str(e.value)

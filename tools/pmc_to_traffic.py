@@ -46,7 +46,17 @@ def main():
                 fb = 2.0 * 1024.0 * sum(fetch) / len(fetch)
                 wb = 1024.0 * sum(write) / max(len(write), 1)
                 res[lib] = {"fetch_bytes": fb, "write_bytes": wb, "launches_sampled": len(fetch)}
-    out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 0`",
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import subprocess
+    import bench  # kernel_sources_sha: bench.py reports whether the kernel sources changed since this collection
+    try:
+        commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+        dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "kmerseek_amd/csrc"], text=True).strip())
+    except Exception:
+        commit, dirty = None, None
+    out = {"commit": commit, "kernel_sources_dirty_vs_commit": dirty, "kernel_sources_sha16": bench.kernel_sources_sha(),
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 0`",
            "correction": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), WRITE_SIZE exact; KiB -> bytes",
            "per_launch_bytes": {k: v["fetch_bytes"] + v["write_bytes"] for k, v in res.items()},
            "detail": res}
