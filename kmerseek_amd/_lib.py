@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # KMERSEEK_AMD_LIB selects another build of the same library (kernel-tuning variants); never a fallback
@@ -122,6 +123,15 @@ def load():
         raise KmerseekLibraryError(
             f"{SO_PATH} not found: build it with `python -m kmerseek_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64, and whichever copy is mapped first serves
+    # both.  If this library pulled in /opt/rocm's copy BEFORE torch was imported, a later `import torch` would bring a
+    # second runtime and ks_ctx_create would then see "no HIP device" (measured: bench.py, round 2).  So when torch is
+    # installed and the process may use it (device memory, streams, torch.distributed), let it load first.
+    if "torch" not in sys.modules and os.environ.get("KS_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     try:
         L = C.CDLL(SO_PATH)
     except OSError as e:  # missing libamdhip64 etc.

@@ -517,16 +517,6 @@ extern "C" int ksh_sketch_fasta(const char *fasta_path, uint32_t ksize, uint32_t
         return fail(2, std::string("Invalid moltype: ") + moltype + ". Must be one of: protein, dayhoff, hp");
     if (ksize == 0 || ksize > 128) return fail(4, "Invalid ksize");
     if (scaled == 0) return fail(12, "scaled must be >= 1");
-    { // zstd / bzip2 / xz: what niffler would have handled and zlib does not
-        FILE *f = fopen(fasta_path, "rb");
-        if (!f) return fail(11, std::string("Parse error: cannot open ") + fasta_path);
-        unsigned char m[6] = {0};
-        const size_t got = fread(m, 1, 6, f);
-        fclose(f);
-        if (got >= 4 && ((m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd) || (m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') ||
-                         (m[0] == 0xfd && m[1] == '7' && m[2] == 'z' && m[3] == 'X')))
-            return fail(11, std::string("Parse error: zstd / bzip2 / xz input is not supported by this build (plain or gzip only): ") + fasta_path);
-    }
     ksh_fasta_sketches *R = new ksh_fasta_sketches();
     std::string e;
     int rc;

@@ -75,6 +75,9 @@ struct sk_args {
     u32 sfix;     // floor(2^48 / ((max_hash >> 32) + 1)): bucket multiplier = (n_windows * sfix) >> 16
     const u8 *lut; // 256-byte encode table for this moltype
     u32 R;         // tile stride in residues (see sk_r_cand)
+    u32 span;      // residues a shared tile covers from tile * R: SK_TILE, or more for the compacting variant (scaled > 1)
+    u32 c_div, c_rcp; // compacting variant: bucket space is positions / c_div (c_rcp = ceil(2^32 / c_div))
+    u64 out_cap;   // capacity of out_hash / out_abund (MODE 0): writes beyond it are dropped and the host repeats larger
     u32 use_ticket; // tile ids from the atomic ticket (1) or from blockIdx.x (0)
     u32 le_cap;    // a sequence whose LOCAL end lies beyond this is not this launch's business
     const u32 *seq_list; // MODE 0: tile_first[n_tiles + 1] (tile -> first sequence); MODE 1: one medium sequence per workgroup
@@ -85,7 +88,8 @@ struct sk_args {
     u32 *counts;    // [n_seqs] unique hashes of medium / long sequences (written by MODE 1 / k_sketch_long, read by MODE 0)
     // decoupled look-back across tiles (MODE 0)
     unsigned long long *tile_status; // [n_tiles] (flag << 62) | value; flag 1 = tile aggregate, 2 = inclusive prefix
-    u32 *ticket;    // [0] dynamic tile id, [1] status bits: 1 = a bounded spin expired, 2 = postings not emitted for some tile
+    u32 *ticket;    // [0] dynamic tile id, [1] status bits: 1 = a bounded spin expired, 2 = postings not emitted for some tile,
+                    //     4 = a compacting tile kept more hashes (or holds more sequences) than its LDS lists take
     u32 n_tiles;
     // optional: postings (hash, sequence) partitioned on the low 8 bits of the join prefix into <= 256 fixed-capacity
     // regions, written while the vector ALU is the bottleneck — the query side's first partition pass of ks_search
@@ -137,7 +141,9 @@ KS_DEV u64 sk_hash_window(const u64 *w /* LDS words starting at pos8 */, u32 k, 
 }
 
 // does the sequence at residue offset `start` with `len` residues end outside its shared tile's LDS window?
-KS_DEV bool sk_deferred(u64 start, u64 len, u32 R) { return start % R + len > SK_MED_MAX; }
+KS_DEV bool sk_deferred(u64 start, u64 len, u32 R, u32 span) { return start % R + len > span - 16; }
+// floor(x / d) for x < 2^32 / d with rcp = ceil(2^32 / d) (d = 1: rcp does not fit, handled apart)
+KS_DEV u32 sk_div(u32 x, u32 d, u32 rcp) { return d == 1 ? x : __umulhi(x, rcp); }
 
 #define SK_SEQ_CAP 254 // sequence boundaries of a tile staged in LDS (tiles with more fall back to global reads)
 // per-element code: sequence (relative to the tile's first, 8 bits) | bucket (12 bits) | arrival slot (12 bits)
@@ -201,9 +207,17 @@ __global__ __launch_bounds__(256) void k_tile_plan(const u64 *offs, u32 n_seqs, 
     tile_first[t] = t == n_tiles ? n_seqs : sk_lower_bound(offs, 0, n_seqs, (u64)t * R);
 }
 
-// MODE 0: shared tiles cut by residue range; MODE 1: one listed medium sequence per workgroup
-template <int MODE>
+// MODE 0: shared tiles cut by residue range; MODE 1: one listed medium sequence per workgroup.
+// CMP 1 (MODE 0 only, scaled > 1): the compacting variant.  FracMinHash drops (scaled - 1) / scaled of the windows, so a
+// tile of SK_TILE positions would run its sort / unique phases — and its prologue, look-back and ~10 barriers — for a
+// fifth of the output.  Instead the tile spans A.span ~ scaled * 3800 residues: it is hashed one SK_TILE-position sub-tile
+// at a time (residue buffer re-staged, next sub-tile's 16 bytes per lane prefetched while the current one is hashed),
+// the windows that pass the threshold are appended to an LDS list (wave scan of the per-lane keep counts + one LDS
+// atomic per wave), and the sort / unique phases run ONCE over the compacted list: the same number of kept hashes per
+// tile as at scaled = 1.  Bucket space shrinks with it: sequence s gets buckets [ls / c + srel, ... + ceil(nw / c)).
+template <int MODE, int CMP>
 __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A) {
+    static_assert(!(CMP && MODE), "the compacting variant is for shared tiles");
     __shared__ __attribute__((aligned(16))) u64 res_w[(SK_TILE + SK_PAD) / 8];
     __shared__ __attribute__((aligned(16))) u32 cnt[SK_TILE / 2 + 4]; // bucket counts, then starts: 16 bits each
     __shared__ u16 dseq[SK_SEQ_CAP + 2];                               // distinct rank at each sequence start
@@ -242,24 +256,31 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     if (tid < 256) lut_s[tid] = A.lut[tid];
     for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
     if (tid < SK_NFLAG) flagbits[tid] = 0;
-    if (tid == 0) { ext_n_heavy = 0; ext_n = 0; }
+    __shared__ u32 n_list_s; // CMP: kept windows appended to the list so far
+    if (tid == 0) { ext_n_heavy = 0; ext_n = 0; n_list_s = 0; }
     if (MODE == 0) {
         // tiles are handed out in ticket order, so every predecessor a look-back waits for is already running
         if (tid == 0) tile_s = ticket_v;
         __syncthreads();
         tile = tile_s;
     }
+    auto load_chunk = [&](u64 g) -> uint4 { // 16 residue bytes at g (16-byte aligned), zero-filled behind the batch
+        if (g + 16 <= A.n_res) return *(const uint4 *)(A.res + g);
+        u32 t[4] = {0, 0, 0, 0};
+        for (u32 b = 0; b < 16 && g + b < A.n_res; b++) t[b >> 2] |= (u32)A.res[g + b] << (8 * (b & 3));
+        return make_uint4(t[0], t[1], t[2], t[3]);
+    };
+    auto stage_chunk = [&](uint4 v) { // through the encode LUT into the tile's residue buffer, 16 B per lane
+        const u32 in[4] = {v.x, v.y, v.z, v.w};
+        u32 o[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            o[d] = (u32)lut_s[in[d] & 255u] | ((u32)lut_s[(in[d] >> 8) & 255u] << 8) |
+                   ((u32)lut_s[(in[d] >> 16) & 255u] << 16) | ((u32)lut_s[in[d] >> 24] << 24);
+        *(uint4 *)(res_b + (size_t)tid * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    };
     uint4 rv = make_uint4(0, 0, 0, 0);
-    if (MODE == 0 && tid < NCH) {
-        const u64 g = (u64)tile * A.R + (u64)tid * 16; // R is a multiple of 16
-        if (g + 16 <= A.n_res) {
-            rv = *(const uint4 *)(A.res + g);
-        } else {
-            u32 t[4] = {0, 0, 0, 0};
-            for (u32 b = 0; b < 16 && g + b < A.n_res; b++) t[b >> 2] |= (u32)A.res[g + b] << (8 * (b & 3));
-            rv = make_uint4(t[0], t[1], t[2], t[3]);
-        }
-    }
+    if (MODE == 0 && tid < NCH) rv = load_chunk((u64)tile * A.R + (u64)tid * 16); // R is a multiple of 16
     u32 s_first, s_end;
     if (MODE == 1) { s_first = A.seq_list[tile]; s_end = s_first + 1; }
     else { s_first = A.seq_list[tile]; s_end = A.seq_list[tile + 1]; }
@@ -286,27 +307,11 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
         if (span_end > g0 + SK_TILE) span_end = g0 + SK_TILE;
         if (tid < NCH) {
             const u64 g = g0 + (u64)tid * 16;
-            if (g < span_end) {
-                if (g + 16 <= A.n_res) {
-                    rv = *(const uint4 *)(A.res + g);
-                } else {
-                    u32 t[4] = {0, 0, 0, 0};
-                    for (u32 b = 0; b < 16 && g + b < A.n_res; b++) t[b >> 2] |= (u32)A.res[g + b] << (8 * (b & 3));
-                    rv = make_uint4(t[0], t[1], t[2], t[3]);
-                }
-            }
+            if (g < span_end) rv = load_chunk(g);
         }
         __syncthreads(); // lut_s
     }
-    if (tid < NCH) {
-        const u32 in[4] = {rv.x, rv.y, rv.z, rv.w};
-        u32 o[4];
-#pragma unroll
-        for (int d = 0; d < 4; d++)
-            o[d] = (u32)lut_s[in[d] & 255u] | ((u32)lut_s[(in[d] >> 8) & 255u] << 8) |
-                   ((u32)lut_s[(in[d] >> 16) & 255u] << 16) | ((u32)lut_s[in[d] >> 24] << 24);
-        *(uint4 *)(res_b + (size_t)tid * 16) = make_uint4(o[0], o[1], o[2], o[3]);
-    }
+    if (tid < NCH) stage_chunk(rv);
     __syncthreads();
 
     SK_STAMP_AT(1);
