@@ -92,6 +92,13 @@ int ks_ctx_synchronize(ks_ctx *ctx);
 int ks_ctx_pool_stats(const ks_ctx *ctx, uint64_t *n_blocks, uint64_t *bytes_held, uint64_t *bytes_in_use,
                       uint64_t *n_mallocs);
 
+/* How often this context had to repeat a sketch batch (results are identical either way; a repeat only costs time):
+ * out[0] = launches repeated because a tile look-back gave up waiting (dispatch order was not blockIdx order; the context
+ *          then takes tile ids from an atomic ticket for good: out[1] = 1),
+ * out[2] = batches repeated with plain tiles because a compacting tile (scaled > 1) kept more hashes than its LDS lists take,
+ * out[3] = batches repeated with window-count sized outputs because they kept more hashes than the expected 1/scaled. */
+int ks_ctx_sketch_stats(const ks_ctx *ctx, uint64_t out[4]);
+
 /* Plain device buffers for callers that have no HIP binding of their own (the *_device entry points take raw
  * device pointers): 256-byte aligned allocations on ctx's device, stream-ordered copies that return when done. */
 int ks_dev_malloc(ks_ctx *ctx, uint64_t bytes, void **out);

@@ -59,6 +59,7 @@ SIGNATURES = {
     "ks_last_error": (C.c_char_p, [_vp]),
     "ks_ctx_stream": (_vp, [_vp]),
     "ks_ctx_synchronize": (C.c_int, [_vp]),
+    "ks_ctx_sketch_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
     "ks_dev_malloc": (C.c_int, [_vp, C.c_uint64, _pp]),
     "ks_dev_free": (C.c_int, [_vp, _vp]),
     "ks_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),

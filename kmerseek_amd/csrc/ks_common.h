@@ -56,6 +56,9 @@ struct ks_ctx {
     // the sketch tiles take their ids from blockIdx.x (dispatch order) until a look-back ever gives up on this context;
     // from then on from an atomic ticket (guaranteed order, one more memory round trip per tile)
     bool sketch_use_ticket = false;
+    // how often a sketch batch had to be repeated: look-back gave up (-> ticket ids from then on), a compacting tile
+    // overflowed its LDS lists (-> plain tiles for that batch), bounded outputs too small (-> window-count sized)
+    u64 sketch_ticket_fallbacks = 0, sketch_compact_fallbacks = 0, sketch_cap_fallbacks = 0;
     // single-launch scans (ks_prims.hip): status ring + ticket counter in device memory, never reset: every entry is
     // tagged with the global tile number that wrote it
     unsigned long long *scan_ring = nullptr;

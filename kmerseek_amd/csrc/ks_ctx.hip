@@ -157,6 +157,13 @@ extern "C" int ks_ctx_pool_stats(const ks_ctx *ctx, uint64_t *n_blocks, uint64_t
     return KS_OK;
 }
 
+extern "C" int ks_ctx_sketch_stats(const ks_ctx *ctx, uint64_t out[4]) {
+    if (!ctx || !out) return KS_ERR_INVALID_ARG;
+    out[0] = ctx->sketch_ticket_fallbacks; out[1] = ctx->sketch_use_ticket ? 1 : 0;
+    out[2] = ctx->sketch_compact_fallbacks; out[3] = ctx->sketch_cap_fallbacks;
+    return KS_OK;
+}
+
 extern "C" int ks_dev_malloc(ks_ctx *ctx, uint64_t bytes, void **out) {
     if (!ctx || !out) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));

@@ -35,7 +35,6 @@
 // R is chosen per batch from these candidates (all multiples of 16) by a measured cost model: a shared tile avoided
 // saves ~26 ns, a deferred sequence costs ~45 ns (MI355X, 1M-protein batches).
 #define SK_NR 8
-__device__ __constant__ const u32 sk_r_cand[SK_NR] = {2544, 2800, 3056, 3312, 3568, 3824, 3952, 4016};
 static const u32 sk_r_cand_host[SK_NR] = {2544, 2800, 3056, 3312, 3568, 3824, 3952, 4016};
 #define SK_PAD 160                  // >= KS_MAX_KSIZE + 24: slack behind the last residue for word reads
 #ifndef SK_MINW
@@ -207,6 +206,47 @@ __global__ __launch_bounds__(256) void k_tile_plan(const u64 *offs, u32 n_seqs, 
     tile_first[t] = t == n_tiles ? n_seqs : sk_lower_bound(offs, 0, n_seqs, (u64)t * R);
 }
 
+// Compacting variant, windows [p0 + H, p0 + H + 4) of a thread: hash, keep what passes the threshold, append to the LDS list
+// (hash -> hlist, sequence relative to the tile's first -> slist): wave scan of the per-lane keep counts, one LDS atomic
+// per wave.  Entries beyond SK_TILE are dropped (the cursor keeps counting: the tile then reports the overflow).
+template <int H>
+KS_DEV void sk_cmp_half(const sk_args &A, const sk_bounds &B, sk_seq &q, const u64 *wl, u32 p0, bool active, u32 s_first, u32 s_end,
+                        u32 lane, u64 *hlist, u8 *slist, u32 *cursor) {
+    u64 h[4];
+    u32 keep = 0, sr = 0; // keep mask of the 4 windows, their sequences (one byte each)
+    if (active) {
+        h[0] = sk_hash_window<H + 0>(wl, A.k, A.seed);
+        h[1] = sk_hash_window<H + 1>(wl, A.k, A.seed);
+        h[2] = sk_hash_window<H + 2>(wl, A.k, A.seed);
+        h[3] = sk_hash_window<H + 3>(wl, A.k, A.seed);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const u32 p = p0 + H + i;
+            while (q.s < s_end && p >= q.le) { q.s++; sk_load_seq(q, A, B, s_end); }
+            if (q.ok && p >= q.ls && p + A.k <= q.le && h[i] != 0 && h[i] <= A.max_hash) {
+                keep |= 1u << i;
+                sr |= (q.s - s_first) << (8 * i);
+            }
+        }
+    }
+    const u32 nk = (u32)__popc(keep);
+    const u32 incl = ks_wave_incl_scan(nk);
+    const u32 wtot = __shfl(incl, 63, 64);
+    u32 wbase = 0;
+    if (lane == 63 && wtot) wbase = atomicAdd(cursor, wtot);
+    wbase = __shfl(wbase, 63, 64);
+    u32 pos = wbase + incl - nk;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (keep & (1u << i)) {
+            if (pos < SK_TILE) {
+                hlist[pos] = h[i];
+                slist[pos] = (u8)(sr >> (8 * i));
+            }
+            pos++;
+        }
+}
+
 // MODE 0: shared tiles cut by residue range; MODE 1: one listed medium sequence per workgroup.
 // CMP 1 (MODE 0 only, scaled > 1): the compacting variant.  FracMinHash drops (scaled - 1) / scaled of the windows, so a
 // tile of SK_TILE positions would run its sort / unique phases — and its prologue, look-back and ~10 barriers — for a
@@ -331,6 +371,81 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     const u64 *wl = res_w + tid; // word at byte q0
     u64 h[SK_E];
     u32 bo[SK_E];
+    if (CMP) {
+        // ---- phase 2, compacting variant: hash sub-tile by sub-tile, keep the windows under the threshold in an LDS list
+        // (hash in tmp, its sequence in the counter words, which are not counting yet), then bucket the compacted list
+        u8 *slist = (u8 *)cnt;
+        const u32 lane = tid & 63u;
+        u32 end_l = B.at(s_end);
+        if (end_l > A.span) end_l = A.span;
+        const u32 n_sub = B.in_lds ? (end_l + SK_TILE - 1) / SK_TILE : 0; // (more sequences than the LDS table holds: flagged below)
+        for (u32 sub = 0; sub < n_sub; sub++) {
+            if (sub > 0) {
+                if (tid < NCH) stage_chunk(rv);
+                __syncthreads();
+            }
+            if (sub + 1 < n_sub && tid < NCH) // next sub-tile's residues travel while this one is hashed
+                rv = load_chunk((u64)tile * A.R + (u64)(sub + 1) * SK_TILE + (u64)tid * 16);
+            const u32 p0 = sub * SK_TILE + q0;
+            const bool active = p0 < end_l;
+            if (active) { // the sequence that holds (or follows) position p0
+                u32 lo = s_first, hi = s_end;
+                while (lo < hi) {
+                    u32 mid = lo + ((hi - lo) >> 1);
+                    if (B.at(mid + 1) > p0) hi = mid; else lo = mid + 1;
+                }
+                q.s = lo;
+                sk_load_seq(q, A, B, s_end);
+            }
+            // two halves of 4 windows: 8 live hashes next to the prefetched residues do not fit the register budget
+            sk_cmp_half<0>(A, B, q, wl, p0, active, s_first, s_end, lane, tmp, slist, &n_list_s);
+            sk_cmp_half<4>(A, B, q, wl, p0, active, s_first, s_end, lane, tmp, slist, &n_list_s);
+            __syncthreads(); // the sub-tile is hashed (its residues may be overwritten) and its appends are visible
+        }
+        const u32 n_list = n_list_s;
+        if (!B.in_lds || n_list > SK_TILE) {
+            // more kept hashes (repeats / skewed input) or more sequences than the LDS lists take: nothing from this launch is
+            // used — the host repeats the batch with the plain variant — but the look-back chain must not stall
+            if (tid == 0) {
+                atomicOr(&A.ticket[1], 4u);
+                __hip_atomic_store(&A.tile_status[tile], (tile == 0 ? SK_FLAG_PRE : SK_FLAG_AGG) | 0ULL, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        // my 8 entries of the list (strided over the threads: conflict-free LDS reads, and every lane gets its share)
+        u32 srl[SK_E];
+#pragma unroll
+        for (int i = 0; i < SK_E; i++) {
+            const u32 idx = (u32)i * SK_THREADS + tid;
+            const bool live = idx < n_list;
+            h[i] = live ? tmp[idx] : 0;
+            srl[i] = live ? (u32)slist[idx] : 0xffffffffu;
+        }
+        __syncthreads(); // list read: tmp is free for the bucket order, cnt for counting
+        for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
+        // per-sequence {first bucket, bucket multiplier} in the (dead) residue buffer: sequence i owns buckets
+        // [ls / c + i, ls / c + i + ceil(nw / c)) — disjoint and ascending, < SK_TILE since span <= c * 3840
+        uint2 *stab = (uint2 *)res_w;
+        for (u32 i = tid; i < ns; i += SK_THREADS) {
+            const u32 ls = loff[i], le = loff[i + 1], len = le - ls;
+            const u32 nw = (len >= A.k && le <= A.le_cap) ? len - A.k + 1 : 0;
+            const u32 nb = sk_div(nw + A.c_div - 1, A.c_div, A.c_rcp);
+            stab[i] = make_uint2(sk_div(ls, A.c_div, A.c_rcp) + i, sk_bucket_mul(nb, A.sfix));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SK_E; i++) {
+            bo[i] = 0xffffffffu;
+            if (srl[i] != 0xffffffffu) {
+                const uint2 t = stab[srl[i]];
+                const u32 b = t.x + __umulhi((u32)(h[i] >> 32), t.y);
+                const u32 sh = (b & 1u) * 16u;
+                const u32 o = (atomicAdd(&cnt[b >> 1], 1u << sh) >> sh) & 0xffffu;
+                bo[i] = (srl[i] << 24) | (b << 12) | o;
+            }
+        }
+    } else
     // a tile's sequences end, on average, two thirds of the way through its SK_TILE positions: the threads behind
     // the last residue (whole waves, mostly) have nothing to hash
     if (q0 < B.at(s_end)) {
@@ -501,7 +616,8 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
         // most one: the last) brings its unique count from the earlier launches into the aggregate
         for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
             const u32 ls = B.at(s), le = B.at(s + 1);
-            const u32 d0 = drank(bstart(ls));
+            // (first bucket of the sequence: its local start, or the compacted base the bucket table holds)
+            const u32 d0 = drank(bstart(CMP ? ((const uint2 *)res_w)[s - s_first].x : ls));
             if (B.in_lds) dseq[s - s_first] = (u16)d0;
             if (le > A.le_cap) {
                 const u32 e = atomicAdd(&ext_n, 1u);
@@ -573,8 +689,10 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
         for (u32 d = tid; d < n_distinct; d += SK_THREADS) {
             u64 pos = base + d;
             for (u32 e = 0; e < ne; e++) pos += ext_d[e] <= d ? ext_cnt[e] : 0;
-            A.out_hash[pos] = tmp[d];
-            A.out_abund[pos] = abund_s[d];
+            if (pos < A.out_cap) { // (capacity-bounded output: the host sees the true total in csr[n_seqs] and repeats larger)
+                A.out_hash[pos] = tmp[d];
+                A.out_abund[pos] = abund_s[d];
+            }
         }
     }
     // ---- phase 9 (optional): the tile's postings, partitioned on one hash digit, into the regions of that digit.
@@ -653,13 +771,14 @@ struct sk_long_args {
 };
 
 // n_cls[0] = medium sequences (own tile), n_cls[1] = long sequences (global-slab path)
-__global__ __launch_bounds__(256) void k_find_long(const u64 *offs, u32 n_seqs, u32 R, u32 *med_ids, u32 *long_ids, u32 *n_cls) {
+__global__ __launch_bounds__(256) void k_find_long(const u64 *offs, u32 n_seqs, u32 R, u32 span, u32 *med_ids, u32 *long_ids, u32 *n_cls) {
     const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
     u32 cls = 2; // 0 medium, 1 long, 2 neither
     if (s < n_seqs) {
         const u64 len = offs[s + 1] - offs[s];
-        if (len > SK_MED_MAX) cls = 1;
-        else if (sk_deferred(offs[s], len, R)) cls = 0;
+        // a sequence that does not end inside its shared tile's span is deferred: to a tile of its own if it fits one,
+        // else to the global-slab path (with the plain span every sequence longer than SK_MED_MAX is deferred)
+        if (len + 16 > span || sk_deferred(offs[s], len, R, span)) cls = len > SK_MED_MAX ? 1 : 0;
     }
     // one atomic per wave and class (the lists are short but every thread would hit the same two counters)
 #pragma unroll
@@ -805,15 +924,22 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
 // before the tile kernel fixed their CSR positions); one workgroup per such sequence.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u64 *offs, const u64 *csr, const u64 *lg_hash,
-                                                    const u32 *lg_abund, u64 *hashes, u32 *abunds, u64 *part_keys,
+                                                    const u32 *lg_abund, u64 *hashes, u32 *abunds, u64 out_cap, u64 *part_keys,
                                                     u32 *part_vals, u32 *part_cursor, u64 part_cap, u32 part_K,
                                                     u32 part_mask, u32 part_sub_shift, u32 *status) {
+    // a compacting tile that overflowed wrote no CSR offsets for its sequences (the host repeats the batch): nothing
+    // here may be trusted then
+    if (__hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) return;
     const u32 s = ids[blockIdx.x];
-    const u64 dst = csr[s], n = csr[s + 1] - dst, src = offs[s];
+    const u64 dst = csr[s], src = offs[s];
+    u64 n = csr[s + 1] - dst;
+    if (n > offs[s + 1] - src) n = offs[s + 1] - src; // (a run is never longer than its sequence)
     for (u64 i = threadIdx.x; i < n; i += 256) {
         const u64 h = lg_hash[src + i];
-        hashes[dst + i] = h;
-        abunds[dst + i] = lg_abund[src + i];
+        if (dst + i < out_cap) {
+            hashes[dst + i] = h;
+            abunds[dst + i] = lg_abund[src + i];
+        }
         if (part_keys) { // long sequences are rare: one device atomic per posting is fine here
             const u32 dg = ((ks_join_prefix(h, part_K) & part_mask) << part_sub_shift) | (blockIdx.x & ((1u << part_sub_shift) - 1u));
             const u64 slot = atomicAdd(&part_cursor[dg], 1u);
@@ -1059,68 +1185,68 @@ int ks_kmerpos_tiles_launch(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32
     return st;
 }
 
-// out[0] = k-mer windows, out[1] = longest sequence, out[2] = long sequences, out[4 + c] = medium (deferred but
-// tile-sized) sequences under tile stride sk_r_cand[c]
-__global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, u32 k, u64 *out) {
-    u64 w = 0, mx = 0, nl = 0;
-    u32 nd[SK_NR];
+// out[0] = k-mer windows, out[1] = longest sequence; under tile stride cand[c] (a tile spans `span` residues from its
+// start): out[4 + c] = medium sequences (deferred, fit a tile of their own), out[4 + SK_NR + c] = long ones (deferred, do not)
+struct sk_cands { u32 r[SK_NR]; };
+__global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, u32 k, u32 span, sk_cands cand, u64 *out) {
+    u64 w = 0, mx = 0;
+    u32 nd[SK_NR], nl[SK_NR];
 #pragma unroll
-    for (int c = 0; c < SK_NR; c++) nd[c] = 0;
+    for (int c = 0; c < SK_NR; c++) { nd[c] = 0; nl[c] = 0; }
     for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n_seqs; s += gridDim.x * blockDim.x) {
         const u64 st = offs[s], len = offs[s + 1] - st;
         w += len >= k ? len - k + 1 : 0;
         mx = len > mx ? len : mx;
-        nl += len > SK_MED_MAX;
-        if (len <= SK_MED_MAX) {
-            // (a sequence no longer than SK_MED_MAX + 1 - R fits wherever it starts: no 64-bit modulo for those; the
-            // two widest strides are only ever taken when EVERY sequence is that short, so they are not counted)
+        // (a sequence no longer than span - 15 - R fits wherever it starts: no 64-bit modulo for those; the two widest
+        // strides are only ever taken when EVERY sequence is that short, so they are not counted)
 #pragma unroll
-            for (int c = 0; c < SK_NR - 2; c++)
-                if (len + sk_r_cand[c] > SK_MED_MAX + 1) nd[c] += sk_deferred(st, len, sk_r_cand[c]) ? 1u : 0u;
-        }
+        for (int c = 0; c < SK_NR - 2; c++)
+            if (len + cand.r[c] + 15 > span) {
+                const bool def = len + 16 > span || sk_deferred(st, len, cand.r[c], span);
+                nd[c] += (def && len <= SK_MED_MAX) ? 1u : 0u;
+                nl[c] += (def && len > SK_MED_MAX) ? 1u : 0u;
+            }
     }
     for (int d = 32; d > 0; d >>= 1) {
         w += __shfl_down(w, d, 64);
-        nl += __shfl_down(nl, d, 64);
         u64 o = __shfl_down(mx, d, 64);
         mx = o > mx ? o : mx;
 #pragma unroll
-        for (int c = 0; c < SK_NR; c++) nd[c] += __shfl_down(nd[c], d, 64);
+        for (int c = 0; c < SK_NR; c++) { nd[c] += __shfl_down(nd[c], d, 64); nl[c] += __shfl_down(nl[c], d, 64); }
     }
     // one set of device atomics per WORKGROUP (they all hit the same few words: per wave they were the whole run time)
-    __shared__ u64 red[4][3 + SK_NR];
+    __shared__ u64 red[4][2 + 2 * SK_NR];
     const u32 wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        red[wave][0] = w; red[wave][1] = mx; red[wave][2] = nl;
+        red[wave][0] = w; red[wave][1] = mx;
 #pragma unroll
-        for (int c = 0; c < SK_NR; c++) red[wave][3 + c] = nd[c];
+        for (int c = 0; c < SK_NR; c++) { red[wave][2 + c] = nd[c]; red[wave][2 + SK_NR + c] = nl[c]; }
     }
     __syncthreads();
-    if (threadIdx.x < 3 + SK_NR) {
+    if (threadIdx.x < 2 + 2 * SK_NR) {
         const u32 j = threadIdx.x;
         u64 v = red[0][j];
         for (u32 q = 1; q < 4; q++) v = j == 1 ? (red[q][j] > v ? red[q][j] : v) : v + red[q][j];
         if (v) {
             if (j == 1) atomicMax((unsigned long long *)&out[1], (unsigned long long)v);
-            else atomicAdd((unsigned long long *)&out[j == 0 ? 0 : (j == 2 ? 2 : 4 + (j - 3))], (unsigned long long)v);
+            else atomicAdd((unsigned long long *)&out[j == 0 ? 0 : 4 + (j - 2)], (unsigned long long)v);
         }
     }
 }
 
-int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, u32 max_seq_len,
-                          const ks_params *p, int part_pbits, ks_sketches **out) {
-    KS_TRY(ks_check_params(ctx, p));
-    if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
-    if (((uintptr_t)d_res & 15) != 0) return ks_fail(ctx, KS_ERR_INVALID_ARG, "d_residues must be 16-byte aligned");
-    (void)max_seq_len; // hint only: the real maximum is measured on the device below
-    KS_HIP(ctx, hipSetDevice(ctx->device));
-
+// One attempt at a batch.  variant bit 0: the compacting tile kernel may be used (scaled > 1); bit 1: outputs sized by the
+// window count (always enough) instead of by the expected number of kept hashes.  *redo comes back non-zero (with KS_OK and
+// nothing produced) when the attempt has to be repeated without the corresponding economy: 1 = a compacting tile
+// overflowed its LDS lists, 2 = the batch kept more hashes than the bounded output arrays hold.
+static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, const ks_params *p, int part_pbits,
+                          int variant, int *redo, ks_sketches **out) {
     ks_sketches *S = new ks_sketches();
     memset(S, 0, sizeof *S);
     S->ctx = ctx;
     S->params = *p;
     S->n_seqs = n_seqs;
     *out = nullptr;
+    *redo = 0;
 
     int st = KS_OK;
     u64 *d_stats = nullptr;
@@ -1129,8 +1255,23 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     unsigned long long *tile_status = nullptr;
     u64 *slab64 = nullptr, *lg_hash = nullptr;
     u32 *slab32 = nullptr, *lg_abund = nullptr;
-    u64 n_med = 0, n_long = 0;
+    u64 n_med = 0, n_long = 0, out_cap = 0;
     u32 real_max = 0, tile_R = sk_r_cand_host[0];
+    // compacting variant: bucket space = positions / c_div, span = residues per shared tile (see k_sketch_tiles<0, 1>)
+    const bool compact = (variant & 1) && p->scaled >= 2 && !getenv("KS_DEBUG_NO_COMPACT");
+    const u32 c_div = compact ? (p->scaled < 64 ? p->scaled : 64u) : 1u;
+    u32 span = SK_TILE;
+    if (compact) {
+        u64 sp = (u64)c_div * 3840; // span / c_div + SK_SEQ_CAP + 1 < SK_TILE buckets
+        if (sp > 8ull * SK_TILE) sp = 8ull * SK_TILE;
+        span = (u32)(sp / 512 * 512);
+        if (const char *f = getenv("KS_DEBUG_SPAN")) { // tuning aid
+            const u32 v = (u32)atoi(f) / 512 * 512;
+            if (v >= SK_TILE && v <= sp) span = v;
+        }
+    }
+    sk_cands cand;
+    for (int c = 0; c < SK_NR; c++) cand.r[c] = sk_r_cand_host[c] + (span - SK_TILE);
 #define SK_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
 #define SK_HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
 
@@ -1144,38 +1285,47 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         return KS_OK;
     }
     {
-        // windows, longest sequence, medium / long counts: one small D2H
-        SK_CHECK(ks_alloc(ctx, &d_stats, 4 + SK_NR));
-        SK_HIPCHECK(hipMemsetAsync(d_stats, 0, (4 + SK_NR) * sizeof(u64), ctx->stream));
+        // windows, longest sequence, medium / long counts per candidate stride: one small D2H
+        SK_CHECK(ks_alloc(ctx, &d_stats, 4 + 2 * SK_NR));
+        SK_HIPCHECK(hipMemsetAsync(d_stats, 0, (4 + 2 * SK_NR) * sizeof(u64), ctx->stream));
         u32 g = (n_seqs + 1023) / 1024;
         if (g > 512) g = 512;
         ks_timer_begin(ctx, "seq_stats");
-        hipLaunchKernelGGL(k_seq_stats, dim3(g), dim3(256), 0, ctx->stream, d_offs, n_seqs, p->ksize, d_stats);
+        hipLaunchKernelGGL(k_seq_stats, dim3(g), dim3(256), 0, ctx->stream, d_offs, n_seqs, p->ksize, span, cand, d_stats);
         ks_timer_end(ctx);
-        SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, (4 + SK_NR) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, (4 + 2 * SK_NR) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
         SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
         S->n_windows = ctx->h_pin[0];
         if (ctx->h_pin[1] > 0xfffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "sequence longer than 2^32 residues"); goto done; }
         real_max = (u32)ctx->h_pin[1];
-        n_long = ctx->h_pin[2];
         {
-            // tile stride: fewest (tiles + 1.75 * deferred sequences), see sk_r_cand
+            // tile stride: fewest (tiles x sub-tiles + 1.75 x medium + 20 x long sequences), see sk_r_cand
             double best = 0;
+            const double per_tile = (double)span / SK_TILE;
             for (int c = 0; c < SK_NR; c++) {
-                if (c >= SK_NR - 2 && (u64)real_max + sk_r_cand_host[c] > SK_MED_MAX + 1) continue; // uncounted strides
-                const double cost = (double)(n_res / sk_r_cand_host[c] + 1) + 1.75 * (double)ctx->h_pin[4 + c];
-                if (c == 0 || cost < best) { best = cost; tile_R = sk_r_cand_host[c]; n_med = ctx->h_pin[4 + c]; }
+                if (c >= SK_NR - 2 && (u64)real_max + cand.r[c] + 15 > span) continue; // uncounted strides
+                const double cost = (double)(n_res / cand.r[c] + 1) * per_tile + 1.75 * (double)ctx->h_pin[4 + c] +
+                                    20.0 * (double)ctx->h_pin[4 + SK_NR + c];
+                if (c == 0 || cost < best) { best = cost; tile_R = cand.r[c]; n_med = ctx->h_pin[4 + c]; n_long = ctx->h_pin[4 + SK_NR + c]; }
             }
-            if (const char *force = getenv("KS_DEBUG_TILE_R")) // tuning aid: index into sk_r_cand (counted strides only)
+            if (const char *force = getenv("KS_DEBUG_TILE_R")) // tuning aid: one of sk_r_cand (counted strides only)
                 for (int c = 0; c < SK_NR - 2; c++)
-                    if (atoi(force) == (int)sk_r_cand_host[c]) { tile_R = sk_r_cand_host[c]; n_med = ctx->h_pin[4 + c]; }
+                    if (atoi(force) == (int)sk_r_cand_host[c]) { tile_R = cand.r[c]; n_med = ctx->h_pin[4 + c]; n_long = ctx->h_pin[4 + SK_NR + c]; }
         }
     }
     {
-        // final arrays sized by the window count (an upper bound on the kept hashes); the tile kernel writes
-        // them in place, so there is no compaction pass
-        SK_CHECK(ks_alloc(ctx, &S->d_hashes, (size_t)S->n_windows));
-        SK_CHECK(ks_alloc(ctx, &S->d_abunds, (size_t)S->n_windows));
+        // The tile kernel writes the final arrays in place (no compaction pass).  At scaled = 1 every window may be kept;
+        // at scaled > 1 the arrays are sized by the expected 1 / scaled of the windows plus a quarter, and a batch that keeps
+        // more (repeats whose hash falls under the threshold) is repeated with the full size.
+        out_cap = S->n_windows;
+        if (!(variant & 2) && p->scaled >= 2) {
+            const u64 want = S->n_windows / p->scaled + S->n_windows / (4ull * p->scaled) + 65536;
+            if (want < out_cap) out_cap = want;
+        }
+        if (const char *f = getenv("KS_DEBUG_OUT_CAP")) // exercises the repeat on small inputs
+            if (!(variant & 2) && strtoull(f, nullptr, 10) < out_cap) out_cap = strtoull(f, nullptr, 10);
+        SK_CHECK(ks_alloc(ctx, &S->d_hashes, (size_t)out_cap));
+        SK_CHECK(ks_alloc(ctx, &S->d_abunds, (size_t)out_cap));
         SK_CHECK(ks_alloc(ctx, &counts, (size_t)n_seqs));
 
         sk_args A;
@@ -1188,6 +1338,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         }
         A.lut = ctx->d_lut + 256 * p->moltype;
         A.counts = counts;
+        A.span = SK_TILE; A.c_div = 1; A.c_rcp = 0; A.out_cap = out_cap;
         SK_CHECK(ks_alloc(ctx, &ticket, 2));
         SK_HIPCHECK(hipMemsetAsync(ticket, 0, 2 * sizeof(u32), ctx->stream));
         A.ticket = ticket;
@@ -1222,15 +1373,16 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             SK_CHECK(ks_alloc(ctx, &n_cls, 2));
             SK_HIPCHECK(hipMemsetAsync(n_cls, 0, 2 * sizeof(u32), ctx->stream));
             ks_timer_begin(ctx, "find_long");
-            hipLaunchKernelGGL(k_find_long, dim3((n_seqs + 255) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, tile_R, med_ids, long_ids, n_cls);
+            hipLaunchKernelGGL(k_find_long, dim3((n_seqs + 255) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, tile_R, span, med_ids, long_ids, n_cls);
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
         }
         if (n_med > 0) {
             sk_args M = A; // (keeps the posting arguments: a medium tile emits its own postings)
             M.out_hash = lg_hash; M.out_abund = lg_abund; M.le_cap = SK_TILE; M.seq_list = med_ids; // local start <= 15, length <= SK_MED_MAX
+            M.out_cap = ~0ULL;
             ks_timer_begin(ctx, "sketch_medium");
-            hipLaunchKernelGGL(k_sketch_tiles<1>, dim3((u32)n_med), dim3(SK_THREADS), 0, ctx->stream, M);
+            hipLaunchKernelGGL((k_sketch_tiles<1, 0>), dim3((u32)n_med), dim3(SK_THREADS), 0, ctx->stream, M);
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
         }
@@ -1265,7 +1417,8 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         ks_timer_begin(ctx, "tile_plan");
         hipLaunchKernelGGL(k_tile_plan, dim3((u32)((n_tiles + 256) / 256)), dim3(256), 0, ctx->stream, d_offs, n_seqs, (u32)n_tiles, tile_R, tile_first);
         ks_timer_end(ctx);
-        A.seq_list = tile_first; A.le_cap = SK_MED_MAX; A.R = tile_R;
+        A.seq_list = tile_first; A.le_cap = span - 16; A.R = tile_R; A.span = span;
+        if (compact) { A.c_div = c_div; A.c_rcp = (u32)(((1ULL << 32) + c_div - 1) / c_div); }
         A.out_hash = S->d_hashes; A.out_abund = S->d_abunds; A.csr = S->d_offsets;
         A.tile_status = tile_status; A.n_tiles = (u32)n_tiles;
         // posting cursors as the medium tiles left them (a repeated launch starts from here)
@@ -1277,12 +1430,21 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             A.use_ticket = (ctx->sketch_use_ticket || attempt == 1) ? 1u : 0u;
             if (attempt == 1) { // the dispatch-order launch gave up a look-back: start the tiles over, ids by ticket
                 ctx->sketch_use_ticket = true;
+                ctx->sketch_ticket_fallbacks++;
                 SK_HIPCHECK(hipMemsetAsync(tile_status, 0, (size_t)n_tiles * sizeof(unsigned long long), ctx->stream));
+                // (keeps the status bits the medium tiles set before the loop — "postings not emitted" — and drops only
+                // the look-back flag of the first attempt)
+                const u32 keep_bits = ((u32 *)(ctx->h_pin + 1))[1] & 2u;
                 SK_HIPCHECK(hipMemsetAsync(ticket, 0, 2 * sizeof(u32), ctx->stream));
+                if (keep_bits) {
+                    ((u32 *)(ctx->h_pin + 2))[0] = keep_bits;
+                    SK_HIPCHECK(hipMemcpyAsync(ticket + 1, ctx->h_pin + 2, sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+                }
                 if (part_snap) SK_HIPCHECK(hipMemcpyAsync(A.part_cursor, part_snap, 2048 * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
             }
             ks_timer_begin(ctx, "sketch_tiles");
-            hipLaunchKernelGGL(k_sketch_tiles<0>, dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
+            if (compact) hipLaunchKernelGGL((k_sketch_tiles<0, 1>), dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
+            else hipLaunchKernelGGL((k_sketch_tiles<0, 0>), dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
 
@@ -1291,14 +1453,14 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                 ks_timer_begin(ctx, "place_long");
                 // medium runs: copy only (their tiles emitted their own postings)
                 hipLaunchKernelGGL(k_place_long, dim3((u32)n_med), dim3(256), 0, ctx->stream, (const u32 *)med_ids, d_offs,
-                                   (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds,
+                                   (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds, out_cap,
                                    (u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u64)0, 0u, 0u, 0u, ticket);
                 ks_timer_end(ctx);
             }
             if (n_long > 0) {
                 ks_timer_begin(ctx, "place_long");
                 hipLaunchKernelGGL(k_place_long, dim3((u32)n_long), dim3(256), 0, ctx->stream, (const u32 *)long_ids, d_offs,
-                                   (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds,
+                                   (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds, out_cap,
                                    A.part_keys, A.part_vals, A.part_cursor, A.part_cap, A.part_K, A.part_mask, A.part_sub_shift, ticket);
                 ks_timer_end(ctx);
             }
@@ -1315,6 +1477,8 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         {
             const u32 status = ((u32 *)(ctx->h_pin + 1))[1];
             if (status & 1u) { st = ks_fail(ctx, KS_ERR_HIP, "sketch: tile look-back timed out"); goto done; }
+            if (status & 4u) { *redo = 1; goto done; }          // a compacting tile overflowed: the plain variant always fits
+            if (S->n_hashes > out_cap) { *redo = 2; goto done; } // more kept hashes than the bounded outputs hold
             if (status & 2u) { // a region overflowed (skewed hashes) or a tile could not code its sequences: no postings,
                                // ks_search repartitions from the CSR instead
                 ks_pool_free(ctx, S->part_keys); ks_pool_free(ctx, S->part_vals); ks_pool_free(ctx, S->part_len);
@@ -1327,7 +1491,7 @@ done:
     ks_pool_free(ctx, counts); ks_pool_free(ctx, tile_first); ks_pool_free(ctx, tile_status); ks_pool_free(ctx, ticket); ks_pool_free(ctx, part_snap);
     ks_pool_free(ctx, d_stats); ks_pool_free(ctx, med_ids); ks_pool_free(ctx, long_ids); ks_pool_free(ctx, n_cls);
     ks_pool_free(ctx, slab64); ks_pool_free(ctx, slab32); ks_pool_free(ctx, lg_hash); ks_pool_free(ctx, lg_abund);
-    if (st != KS_OK) {
+    if (st != KS_OK || *redo) {
         (void)hipStreamSynchronize(ctx->stream);
         ks_sketches_free(S);
         return st;
@@ -1336,4 +1500,24 @@ done:
     return KS_OK;
 #undef SK_CHECK
 #undef SK_HIPCHECK
+}
+
+int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, u32 max_seq_len,
+                          const ks_params *p, int part_pbits, ks_sketches **out) {
+    KS_TRY(ks_check_params(ctx, p));
+    if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
+    if (((uintptr_t)d_res & 15) != 0) return ks_fail(ctx, KS_ERR_INVALID_ARG, "d_residues must be 16-byte aligned");
+    (void)max_seq_len; // hint only: the real maximum is measured on the device
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    // economies first (compacting tiles, outputs sized by the expected kept count); a batch that defeats one — repeats
+    // whose hash falls under the threshold — is repeated without it (at most twice; the last variant always fits)
+    int variant = 1;
+    for (int round = 0; round < 3; round++) {
+        int redo = 0;
+        const int st = sketch_attempt(ctx, d_res, d_offs, n_seqs, n_res, p, part_pbits, variant, &redo, out);
+        if (st != KS_OK || !redo) return st;
+        if (redo == 1) { variant &= ~1; ctx->sketch_compact_fallbacks++; }
+        else { variant |= 2; ctx->sketch_cap_fallbacks++; }
+    }
+    return ks_fail(ctx, KS_ERR_HIP, "sketch: no variant fitted the batch");
 }

@@ -133,6 +133,12 @@ class Context:
         self._check(self._L.ks_ctx_pool_stats(self._h, *[C.byref(x) for x in v]))
         return dict(zip(("blocks", "bytes_held", "bytes_in_use", "mallocs"), (int(x.value) for x in v)))
 
+    def sketch_stats(self) -> Dict[str, int]:
+        """Repeats this context needed so far (see ks_ctx_sketch_stats): results never depend on them, run time does."""
+        v = (C.c_uint64 * 4)()
+        self._check(self._L.ks_ctx_sketch_stats(self._h, C.byref(v)))
+        return {"ticket_fallbacks": int(v[0]), "uses_ticket": int(v[1]), "compact_fallbacks": int(v[2]), "cap_fallbacks": int(v[3])}
+
     # ---- sketch ----
     def sketch_batch(self, residues: np.ndarray, offsets: np.ndarray, ksize: int, scaled: int, moltype: str,
                      seed: int = SEED) -> "Sketches":
