@@ -139,8 +139,10 @@ int ks_sketch_batch(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_of
                     uint32_t n_seqs, const ks_params *params, ks_sketches **out);
 
 /* Same, with residues / seq_offsets already resident in device memory (HBM) on ctx's device.
- * n_residues = seq_offsets[n_seqs]; max_seq_len >= the longest sequence (0 = let the library
- * compute it, which costs one device->host sync). */
+ * n_residues = seq_offsets[n_seqs].  max_seq_len: an upper bound on the longest sequence of the batch, or 0.
+ * With a bound the launches are planned on the host and the call synchronises once, at its end; with 0 the
+ * library measures the batch first (one more device->host round trip, and a tile stride fitted to the batch).
+ * A bound smaller than the longest sequence is detected and fails with KS_ERR_INVALID_ARG (no output). */
 int ks_sketch_batch_device(ks_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_seq_offsets,
                            uint32_t n_seqs, uint64_t n_residues, uint32_t max_seq_len,
                            const ks_params *params, ks_sketches **out);

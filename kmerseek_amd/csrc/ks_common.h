@@ -53,6 +53,9 @@ struct ks_ctx {
     u64 *h_pin = nullptr; // 64 x u64
     // matched posting pairs of recent searches (+ slack): sizes the next search's match list so the join runs once
     u64 pair_cap_hint = 0;
+    // hit rows of recent searches (+ slack): sizes the next search's row arrays so that the row count can be read with the
+    // final synchronisation instead of a round trip of its own
+    u64 rows_hint = 0;
     // the sketch tiles take their ids from blockIdx.x (dispatch order) until a look-back ever gives up on this context;
     // from then on from an atomic ticket (guaranteed order, one more memory round trip per tile)
     bool sketch_use_ticket = false;

@@ -272,6 +272,10 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
 #pragma unroll
             for (int e = 0; e < JN_E; e++) {
                 const u64 i = q0 + (u64)e * JN_THREADS + tid;
+                info[e] = 0;
+                // (uniform: a bucket with few query postings — small batches, query shards of a strong-scaling run — fills
+                // only the first slots of the round, and an empty slot would cost the same 13 LDS probes as a full one)
+                if (q0 + (u64)e * JN_THREADS >= qe) continue;
                 u32 lo = jn_lower_bound_lds(lk, n, h[e]);
                 u32 c = 0;
                 if (i < qe)
@@ -367,8 +371,10 @@ __global__ __launch_bounds__(256) void k_pair_rows(const u64 *keys, const u32 *h
 // One pass over the sorted match list, coalesced: element i belongs to row hidx[i] (+1 if it is not a head, -1 based);
 // a wave sums abundance and count per row with a segmented shuffle scan and the last lane of each row segment adds the
 // partial to the row (rows span waves, so the adds are atomic: ~2 per wave).  Heads write the ids.
+// Rows beyond `rows_cap` are dropped (the row arrays are sized from the previous search's row count; the host repeats
+// this launch with exact arrays when the true count — known only after the scan — is larger).
 __global__ __launch_bounds__(256) void k_pair_reduce(const u64 *keys, const u32 *vals, const u32 *hidx, u64 n, u32 *qid,
-                                                     u32 *tid, u32 *isect, unsigned long long *nw, int tbits, int abits) {
+                                                     u32 *tid, u32 *isect, unsigned long long *nw, int tbits, int abits, u32 rows_cap) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 lane = threadIdx.x & 63;
     const bool live = i < n;
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(256) void k_pair_reduce(const u64 *keys, const u32 
         row = hidx[i] - (head ? 0u : 1u);
         w = vals ? (u64)vals[i] : (k & ((1ULL << abits) - 1ULL));
         c = 1;
-        if (head) {
+        if (head && row < rows_cap) {
             const u64 ids = k >> abits;
             qid[row] = (u32)(ids >> tbits);
             tid[row] = (u32)(ids & ((1ULL << tbits) - 1ULL));
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256) void k_pair_reduce(const u64 *keys, const u32 
     }
     const u32 nrow = __shfl_down(row, 1, 64);
     // (plain stores for rows that sit wholly inside a wave were measured slower than these fire-and-forget adds)
-    if (live && (lane == 63 || nrow != row)) {
+    if (live && (lane == 63 || nrow != row) && row < rows_cap) {
         atomicAdd(&isect[row], c);
         atomicAdd(&nw[row], (unsigned long long)w);
     }
@@ -574,22 +580,37 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         hipLaunchKernelGGL(k_pair_heads, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, n_pairs, heads, abits);
         ks_timer_end(ctx);
         SE_CHECK(ks_scan_u32_inplace(ctx, heads, n_pairs, d_nrows));
-        SE_HIP(hipMemcpyAsync(ctx->h_pin, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-        SE_HIP(hipStreamSynchronize(ctx->stream));
-        const u32 n_rows = *(u32 *)ctx->h_pin;
+        // The row count is only known on the device here.  Instead of a round trip before the reduce, the row arrays take
+        // their size from the previous search of this context (+ 25 %) and the count is read with the final
+        // synchronisation; a search that produced more rows than that repeats the (cheap) reduce with exact arrays.
+        u64 rows_cap = n_pairs;
+        if (ctx->rows_hint && ctx->rows_hint < rows_cap && !getenv("KS_DEBUG_NO_ROWS_HINT")) rows_cap = ctx->rows_hint;
+        u32 n_rows = 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            SE_CHECK(ks_alloc(ctx, &H->d_qid, (size_t)rows_cap)); SE_CHECK(ks_alloc(ctx, &H->d_tid, (size_t)rows_cap));
+            SE_CHECK(ks_alloc(ctx, &H->d_isect, (size_t)rows_cap)); SE_CHECK(ks_alloc(ctx, &H->d_nw, (size_t)rows_cap));
+            SE_HIP(hipMemsetAsync(H->d_isect, 0, (size_t)rows_cap * sizeof(u32), ctx->stream));
+            SE_HIP(hipMemsetAsync(H->d_nw, 0, (size_t)rows_cap * sizeof(u64), ctx->stream));
+            ks_timer_begin(ctx, "pair_reduce");
+            hipLaunchKernelGGL(k_pair_reduce, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv, (const u32 *)heads,
+                               n_pairs, H->d_qid, H->d_tid, H->d_isect, (unsigned long long *)H->d_nw, tbits, abits, (u32)rows_cap);
+            ks_timer_end(ctx);
+            SE_HIP(hipGetLastError());
+            SE_HIP(hipMemcpyAsync(ctx->h_pin, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+            SE_CHECK(ks_scan_status_fetch(ctx));
+            SE_HIP(hipStreamSynchronize(ctx->stream));
+            SE_CHECK(ks_scan_status_check(ctx));
+            n_rows = *(u32 *)ctx->h_pin;
+            if (n_rows <= rows_cap) break;
+            ks_pool_free(ctx, H->d_qid); ks_pool_free(ctx, H->d_tid); ks_pool_free(ctx, H->d_isect); ks_pool_free(ctx, H->d_nw);
+            H->d_qid = H->d_tid = H->d_isect = nullptr; H->d_nw = nullptr;
+            rows_cap = n_rows;
+        }
         H->n_hits = n_rows;
-        SE_CHECK(ks_alloc(ctx, &H->d_qid, (size_t)n_rows)); SE_CHECK(ks_alloc(ctx, &H->d_tid, (size_t)n_rows));
-        SE_CHECK(ks_alloc(ctx, &H->d_isect, (size_t)n_rows)); SE_CHECK(ks_alloc(ctx, &H->d_nw, (size_t)n_rows));
-        SE_HIP(hipMemsetAsync(H->d_isect, 0, (size_t)n_rows * sizeof(u32), ctx->stream));
-        SE_HIP(hipMemsetAsync(H->d_nw, 0, (size_t)n_rows * sizeof(u64), ctx->stream));
-        ks_timer_begin(ctx, "pair_reduce");
-        hipLaunchKernelGGL(k_pair_reduce, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv, (const u32 *)heads,
-                           n_pairs, H->d_qid, H->d_tid, H->d_isect, (unsigned long long *)H->d_nw, tbits, abits);
-        ks_timer_end(ctx);
-        SE_HIP(hipGetLastError());
-        SE_CHECK(ks_scan_status_fetch(ctx));
-        SE_HIP(hipStreamSynchronize(ctx->stream));
-        SE_CHECK(ks_scan_status_check(ctx));
+        {
+            const u64 want = (u64)n_rows + n_rows / 4 + 4096;
+            ctx->rows_hint = want > ctx->rows_hint / 2 ? want : ctx->rows_hint / 2; // follows growth at once, decays slowly
+        }
     }
 done:
     ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);

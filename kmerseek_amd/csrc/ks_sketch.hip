@@ -79,7 +79,9 @@ struct sk_args {
     u64 out_cap;   // capacity of out_hash / out_abund (MODE 0): writes beyond it are dropped and the host repeats larger
     u32 use_ticket; // tile ids from the atomic ticket (1) or from blockIdx.x (0)
     u32 le_cap;    // a sequence whose LOCAL end lies beyond this is not this launch's business
-    const u32 *seq_list; // MODE 0: tile_first[n_tiles + 1] (tile -> first sequence); MODE 1: one medium sequence per workgroup
+    const u32 *seq_list; // MODE 0: tile_first[n_tiles + 1] (tile -> first sequence); MODE 1: the medium sequences
+    const u32 *n_list;   // MODE 1: device-resident length of seq_list
+    u32 n_list_cap;      // ... and the allocated length (the smaller one counts)
     // MODE 0 writes the final CSR directly: hashes / abunds at csr positions, csr[s] per sequence
     u64 *out_hash;  // MODE 0: final hashes [n_windows]; MODE 1: lg_hash [n_res] (run of sequence s starts at offs[s])
     u32 *out_abund;
@@ -256,7 +258,7 @@ KS_DEV void sk_cmp_half(const sk_args &A, const sk_bounds &B, sk_seq &q, const u
 // atomic per wave), and the sort / unique phases run ONCE over the compacted list: the same number of kept hashes per
 // tile as at scaled = 1.  Bucket space shrinks with it: sequence s gets buckets [ls / c + srel, ... + ceil(nw / c)).
 template <int MODE, int CMP>
-__global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A) {
+KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     static_assert(!(CMP && MODE), "the compacting variant is for shared tiles");
     __shared__ __attribute__((aligned(16))) u64 res_w[(SK_TILE + SK_PAD) / 8];
     __shared__ __attribute__((aligned(16))) u32 cnt[SK_TILE / 2 + 4]; // bucket counts, then starts: 16 bits each
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     __shared__ u32 ext_n_heavy; // heavy-bucket queue cursor
     __shared__ u32 ext_seq[4], ext_cnt[4], ext_d[4];
     __shared__ unsigned long long base_s;
-    u32 tile = blockIdx.x;
+    u32 tile = tile_in;
     constexpr u32 NCH = (SK_TILE + SK_PAD) / 16; // 16-byte chunks of a staged tile
     static_assert(NCH <= SK_THREADS, "one staging chunk per thread");
     // A workgroup's start is a chain of dependent memory latencies (ticket -> tile plan -> offsets); everything that
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
     // an observed property of the dispatcher, not a documented one: the look-back's bounded spin turns a violation
     // into a flag, and the host then repeats the launch with ids drawn from an atomic ticket (use_ticket), which
     // guarantees the order by construction.
-    if (MODE == 0 && tid == 0) ticket_v = A.use_ticket ? atomicAdd(&A.ticket[0], 1u) : blockIdx.x;
+    if (MODE == 0 && tid == 0) ticket_v = A.use_ticket ? atomicAdd(&A.ticket[0], 1u) : tile_in;
     if (tid < 256) lut_s[tid] = A.lut[tid];
     for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
     if (tid < SK_NFLAG) flagbits[tid] = 0;
@@ -598,6 +600,58 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
         }
     };
 
+    // The tile's postings (hash, sequence), partitioned on one hash digit, into the regions of that digit: digit-sort the
+    // representatives through tmp so that each digit leaves as one run.  LDS scratch: tmp, cnt (as 16-bit sequence codes),
+    // loff (as digit bins) — all free between the publication of the aggregate and stage_reps() when the boundaries are
+    // served from dseq.  The rank inside (tile, digit) goes into the dead bucket / slot bits of the element code.
+    __shared__ u32 gbase[256];
+    auto emit_postings = [&]() {
+        u32 *bins = loff;               // [256] count per digit, then exclusive start inside the tile
+        u16 *qrel = (u16 *)cnt;         // sequence (relative) of the element staged at tmp[pos]
+        __syncthreads();                // whoever read tmp / cnt / loff before is done
+        if (tid < 256) bins[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SK_E; i++)
+            if (pa[i] & 1u)
+                bo[i] = (bo[i] & 0xff000000u) | atomicAdd(&bins[ks_join_prefix(h[i], A.part_K) & A.part_mask], 1u);
+        __syncthreads();
+        {
+            const u32 c = tid < 256 ? bins[tid] : 0;
+            u32 total;
+            const u32 ex = ks_block_excl_scan(c, scan_smem, &total);
+            if (tid < 256) {
+                u32 off = 0;
+                if (c) {
+                    off = atomicAdd(&A.part_cursor[(tid << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u))], c);
+                    if ((u64)off + c > A.part_cap) atomicOr(&A.ticket[1], 2u); // region full: host falls back
+                }
+                gbase[tid] = off;
+                bins[tid] = ex;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < SK_E; i++)
+            if (pa[i] & 1u) {
+                const u32 pos = bins[ks_join_prefix(h[i], A.part_K) & A.part_mask] + (bo[i] & 0xffffffu);
+                tmp[pos] = h[i];
+                qrel[pos] = (u16)SK_BO_S(bo[i]);
+            }
+        __syncthreads();
+        for (u32 i = tid; i < n_distinct; i += SK_THREADS) {
+            const u64 hh = tmp[i];
+            const u32 dg = ks_join_prefix(hh, A.part_K) & A.part_mask;
+            const u64 slot = (u64)gbase[dg] + (i - bins[dg]);
+            if (slot < A.part_cap) {
+                // (workgroups go round-robin to the XCDs, so blockIdx.x & 7 names the L2 these writes go through)
+                const u64 at = (u64)((dg << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u))) * A.part_cap + slot;
+                A.part_keys[at] = hh;
+                A.part_vals[at] = s_first + qrel[i];
+            }
+        }
+    };
+
     if (MODE == 1) {
         if (tid == 0) A.counts[s_first] = n_distinct;
         __syncthreads();
@@ -632,6 +686,14 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
         if (tid == 0)
             __hip_atomic_store(&A.tile_status[tile], (tile == 0 ? SK_FLAG_PRE : SK_FLAG_AGG) | agg, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+        // The look-back below waits for the predecessors' aggregates, and a predecessor publishes only after its own rank /
+        // unique phases: 11 % of a workgroup's life was spent in that wait (per-phase clocks, profiles/).  The postings do
+        // not need the tile's CSR base, so they are emitted HERE, between publication and look-back: by the time wave 0 looks
+        // back, its predecessors have long published.
+        if (A.part_keys && B.in_lds) {
+            emit_postings();
+            __syncthreads(); // tmp / cnt are staged over next
+        }
         if (B.in_lds) { // bucket starts are dead (dseq holds what the CSR needs): stage now, look back after
             stage_reps();
             __syncthreads();
@@ -695,60 +757,30 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
             }
         }
     }
-    // ---- phase 9 (optional): the tile's postings, partitioned on one hash digit, into the regions of that digit.
-    // Everything LDS is free again: digit-sort the representatives through tmp so each digit leaves as one run.
+    // ---- phase 9 (optional): the tile's postings (medium tiles; shared tiles emitted theirs before the look-back)
     if (A.part_keys) {
         if (!B.in_lds) { // sequence ids do not fit the element code: let the host repartition this batch
             if (tid == 0) atomicOr(&A.ticket[1], 2u);
-        } else {
-            u32 *bins = loff;               // [256] count per digit, then exclusive start inside the tile
-            __shared__ u32 gbase[256];
-            u16 *qrel = (u16 *)cnt;         // sequence (relative) of the element staged at tmp[pos]
-            __syncthreads();                // phase 8 finished reading tmp / abund_s
-            if (tid < 256) bins[tid] = 0;
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < SK_E; i++)
-                if (pa[i] & 1u) // rank inside (tile, digit) replaces the abundance (already staged)
-                    pa[i] = (pa[i] & 0xffffu) | (atomicAdd(&bins[ks_join_prefix(h[i], A.part_K) & A.part_mask], 1u) << 16);
-            __syncthreads();
-            {
-                const u32 c = tid < 256 ? bins[tid] : 0;
-                u32 total;
-                const u32 ex = ks_block_excl_scan(c, scan_smem, &total);
-                if (tid < 256) {
-                    u32 off = 0;
-                    if (c) {
-                        off = atomicAdd(&A.part_cursor[(tid << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u))], c);
-                        if ((u64)off + c > A.part_cap) atomicOr(&A.ticket[1], 2u); // region full: host falls back
-                    }
-                    gbase[tid] = off;
-                    bins[tid] = ex;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < SK_E; i++)
-                if (pa[i] & 1u) {
-                    const u32 pos = bins[ks_join_prefix(h[i], A.part_K) & A.part_mask] + (pa[i] >> 16);
-                    tmp[pos] = h[i];
-                    qrel[pos] = (u16)SK_BO_S(bo[i]);
-                }
-            __syncthreads();
-            for (u32 i = tid; i < n_distinct; i += SK_THREADS) {
-                const u64 hh = tmp[i];
-                const u32 dg = ks_join_prefix(hh, A.part_K) & A.part_mask;
-                const u64 slot = (u64)gbase[dg] + (i - bins[dg]);
-                if (slot < A.part_cap) {
-                    // (workgroups go round-robin to the XCDs, so blockIdx.x & 7 names the L2 these writes go through)
-                    const u64 at = (u64)((dg << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u))) * A.part_cap + slot;
-                    A.part_keys[at] = hh;
-                    A.part_vals[at] = s_first + qrel[i];
-                }
-            }
+        } else if (MODE == 1) {
+            emit_postings();
         }
     }
     SK_STAMP_AT(8);
+}
+
+// MODE 0: one shared tile per workgroup, ids in dispatch order (the look-back relies on it).  MODE 1: the medium
+// sequences — their number is only known on the device (*A.n_list), so a fixed grid strides over the list.
+template <int MODE, int CMP>
+__global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A) {
+    if (MODE == 1) {
+        const u32 n = *A.n_list < A.n_list_cap ? *A.n_list : A.n_list_cap;
+        for (u32 t = blockIdx.x; t < n; t += gridDim.x) {
+            sk_tile_body<MODE, CMP>(A, t);
+            __syncthreads(); // the next sequence re-initialises the LDS state
+        }
+    } else {
+        sk_tile_body<MODE, CMP>(A, blockIdx.x);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -758,6 +790,7 @@ struct sk_long_args {
     sk_args a;
     const u32 *long_ids;
     const u32 *n_long;
+    u32 long_cap;  // allocated entries of long_ids
     u32 max_len;   // slab sizing
     u64 *slab_keys; // [grid][max_len]   window-order hashes (0 = dropped)
     u64 *slab_tmp;  // [grid][max_len]   bucket-ordered hashes
@@ -771,7 +804,8 @@ struct sk_long_args {
 };
 
 // n_cls[0] = medium sequences (own tile), n_cls[1] = long sequences (global-slab path)
-__global__ __launch_bounds__(256) void k_find_long(const u64 *offs, u32 n_seqs, u32 R, u32 span, u32 *med_ids, u32 *long_ids, u32 *n_cls) {
+__global__ __launch_bounds__(256) void k_find_long(const u64 *offs, u32 n_seqs, u32 R, u32 span, u32 *med_ids, u32 *long_ids, u32 *n_cls,
+                                                   u32 med_cap, u32 long_cap) {
     const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
     u32 cls = 2; // 0 medium, 1 long, 2 neither
     if (s < n_seqs) {
@@ -789,7 +823,9 @@ __global__ __launch_bounds__(256) void k_find_long(const u64 *offs, u32 n_seqs, 
         u32 base = 0;
         if ((threadIdx.x & 63) == leader) base = atomicAdd(&n_cls[c], (u32)__popcll(m));
         base = __shfl(base, (int)leader, 64);
-        if (cls == c) (c == 0 ? med_ids : long_ids)[base + ks_lane_lt_count(m)] = s;
+        // (the lists are sized from the caller's max_seq_len when it gave one: an entry beyond them means the hint was too
+        // small — dropped here, reported by the host, which compares the hint with the measured maximum)
+        if (cls == c && base + ks_lane_lt_count(m) < (c == 0 ? med_cap : long_cap)) (c == 0 ? med_ids : long_ids)[base + ks_lane_lt_count(m)] = s;
     }
 }
 
@@ -819,7 +855,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
     const u32 tid = threadIdx.x;
     u8 *res_b = (u8 *)res_w;
     if (tid < 256) lut_s[tid] = A.lut[tid];
-    const u32 n_long = L.n_long[1];
+    const u32 n_long = L.n_long[1] < L.long_cap ? L.n_long[1] : L.long_cap;
     const u64 slab = (u64)blockIdx.x * ((u64)L.max_len + 1);
     u64 *keys = L.slab_keys + slab, *tmp = L.slab_tmp + slab, *sorted = L.slab_sorted + slab;
     u32 *cnt = L.slab_cnt + slab, *ord = L.slab_ord + slab, *flag = L.slab_flag + slab, *abd = L.slab_ab + slab;
@@ -827,6 +863,10 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
     for (u32 li = blockIdx.x; li < n_long; li += gridDim.x) {
         const u32 s = L.long_ids[li];
         const u64 b = A.offs[s], e = A.offs[s + 1];
+        if (e - b > L.max_len) { // the caller's max_seq_len hint was too small: the host reports it (real maximum != hint)
+            if (tid == 0) A.counts[s] = 0;
+            continue;
+        }
         const u32 len = (u32)(e - b);
         const u32 nw = len >= A.k ? len - A.k + 1 : 0;
         const u32 mul = sk_bucket_mul(nw, A.sfix);
@@ -923,14 +963,16 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
 // CSR assembly: only medium / long sequences need a copy (their runs were produced in side buffers
 // before the tile kernel fixed their CSR positions); one workgroup per such sequence.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u64 *offs, const u64 *csr, const u64 *lg_hash,
+__global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u32 *n_ids_dev, u32 ids_cap, const u64 *offs, const u64 *csr, const u64 *lg_hash,
                                                     const u32 *lg_abund, u64 *hashes, u32 *abunds, u64 out_cap, u64 *part_keys,
                                                     u32 *part_vals, u32 *part_cursor, u64 part_cap, u32 part_K,
                                                     u32 part_mask, u32 part_sub_shift, u32 *status) {
     // a compacting tile that overflowed wrote no CSR offsets for its sequences (the host repeats the batch): nothing
     // here may be trusted then
     if (__hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) return;
-    const u32 s = ids[blockIdx.x];
+    const u32 n_ids = *n_ids_dev < ids_cap ? *n_ids_dev : ids_cap; // (only known on the device: a fixed grid strides over the list)
+    for (u32 li = blockIdx.x; li < n_ids; li += gridDim.x) {
+    const u32 s = ids[li];
     const u64 dst = csr[s], src = offs[s];
     u64 n = csr[s + 1] - dst;
     if (n > offs[s + 1] - src) n = offs[s + 1] - src; // (a run is never longer than its sequence)
@@ -950,6 +992,7 @@ __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u64 *o
                 atomicOr(&status[1], 2u);
             }
         }
+    }
     }
 }
 
@@ -1238,8 +1281,8 @@ __global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, 
 // window count (always enough) instead of by the expected number of kept hashes.  *redo comes back non-zero (with KS_OK and
 // nothing produced) when the attempt has to be repeated without the corresponding economy: 1 = a compacting tile
 // overflowed its LDS lists, 2 = the batch kept more hashes than the bounded output arrays hold.
-static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, const ks_params *p, int part_pbits,
-                          int variant, int *redo, ks_sketches **out) {
+static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, u32 max_seq_len, const ks_params *p,
+                          int part_pbits, int variant, int *redo, ks_sketches **out) {
     ks_sketches *S = new ks_sketches();
     memset(S, 0, sizeof *S);
     S->ctx = ctx;
@@ -1255,8 +1298,10 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     unsigned long long *tile_status = nullptr;
     u64 *slab64 = nullptr, *lg_hash = nullptr;
     u32 *slab32 = nullptr, *lg_abund = nullptr;
-    u64 n_med = 0, n_long = 0, out_cap = 0;
+    u64 n_med = 0, n_long = 0, out_cap = 0; // (with a plan from max_seq_len: upper bounds, the true counts stay on the device)
+    u64 win_bound = 0;                      // k-mer windows of the batch, or an upper bound (n_res) until the final read
     u32 real_max = 0, tile_R = sk_r_cand_host[0];
+    const bool planned = max_seq_len > 0 && !getenv("KS_DEBUG_NO_PLAN");
     // compacting variant: bucket space = positions / c_div, span = residues per shared tile (see k_sketch_tiles<0, 1>)
     const bool compact = (variant & 1) && p->scaled >= 2 && !getenv("KS_DEBUG_NO_COMPACT");
     const u32 c_div = compact ? (p->scaled < 64 ? p->scaled : 64u) : 1u;
@@ -1285,7 +1330,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         return KS_OK;
     }
     {
-        // windows, longest sequence, medium / long counts per candidate stride: one small D2H
+        // windows, longest sequence, medium / long counts per candidate stride
         SK_CHECK(ks_alloc(ctx, &d_stats, 4 + 2 * SK_NR));
         SK_HIPCHECK(hipMemsetAsync(d_stats, 0, (4 + 2 * SK_NR) * sizeof(u64), ctx->stream));
         u32 g = (n_seqs + 1023) / 1024;
@@ -1293,12 +1338,14 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         ks_timer_begin(ctx, "seq_stats");
         hipLaunchKernelGGL(k_seq_stats, dim3(g), dim3(256), 0, ctx->stream, d_offs, n_seqs, p->ksize, span, cand, d_stats);
         ks_timer_end(ctx);
-        SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, (4 + 2 * SK_NR) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-        SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
-        S->n_windows = ctx->h_pin[0];
-        if (ctx->h_pin[1] > 0xfffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "sequence longer than 2^32 residues"); goto done; }
-        real_max = (u32)ctx->h_pin[1];
-        {
+        if (!planned) {
+            // no upper bound on the sequence length from the caller: the plan (tile stride, deferred sequences, slab size)
+            // comes from the batch itself, at the price of one device -> host round trip before the tiles are launched
+            SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, (4 + 2 * SK_NR) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+            SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
+            win_bound = ctx->h_pin[0];
+            if (ctx->h_pin[1] > 0xfffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "sequence longer than 2^32 residues"); goto done; }
+            real_max = (u32)ctx->h_pin[1];
             // tile stride: fewest (tiles x sub-tiles + 1.75 x medium + 20 x long sequences), see sk_r_cand
             double best = 0;
             const double per_tile = (double)span / SK_TILE;
@@ -1311,7 +1358,21 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             if (const char *force = getenv("KS_DEBUG_TILE_R")) // tuning aid: one of sk_r_cand (counted strides only)
                 for (int c = 0; c < SK_NR - 2; c++)
                     if (atoi(force) == (int)sk_r_cand_host[c]) { tile_R = cand.r[c]; n_med = ctx->h_pin[4 + c]; n_long = ctx->h_pin[4 + SK_NR + c]; }
+        } else {
+            // max_seq_len given: everything the launches need follows from it, and what is only known on the device (how
+            // many sequences are deferred) is read there by kernels with fixed grids.  The widest stride whose tiles hold
+            // every sequence wherever it starts, else the stride the cost model picks for proteome-like batches.
+            real_max = max_seq_len;
+            win_bound = n_res;
+            tile_R = cand.r[3];
+            for (int c = SK_NR - 1; c >= SK_NR - 2; c--)
+                if ((u64)real_max + cand.r[c] + 15 <= span) { tile_R = cand.r[c]; break; }
+            const bool may_defer = (u64)real_max + tile_R + 15 > span;
+            const u64 n_t = n_res / tile_R + 1; // at most one deferred sequence per tile (the last that starts in it)
+            n_med = may_defer ? n_t : 0;
+            n_long = (may_defer && real_max > SK_MED_MAX) ? n_t : 0;
         }
+        S->n_windows = win_bound;
     }
     {
         // The tile kernel writes the final arrays in place (no compaction pass).  At scaled = 1 every window may be kept;
@@ -1373,7 +1434,8 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             SK_CHECK(ks_alloc(ctx, &n_cls, 2));
             SK_HIPCHECK(hipMemsetAsync(n_cls, 0, 2 * sizeof(u32), ctx->stream));
             ks_timer_begin(ctx, "find_long");
-            hipLaunchKernelGGL(k_find_long, dim3((n_seqs + 255) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, tile_R, span, med_ids, long_ids, n_cls);
+            hipLaunchKernelGGL(k_find_long, dim3((n_seqs + 255) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, tile_R, span, med_ids, long_ids, n_cls,
+                               (u32)n_med, (u32)n_long);
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
         }
@@ -1381,8 +1443,9 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             sk_args M = A; // (keeps the posting arguments: a medium tile emits its own postings)
             M.out_hash = lg_hash; M.out_abund = lg_abund; M.le_cap = SK_TILE; M.seq_list = med_ids; // local start <= 15, length <= SK_MED_MAX
             M.out_cap = ~0ULL;
+            M.n_list = n_cls; M.n_list_cap = (u32)n_med;
             ks_timer_begin(ctx, "sketch_medium");
-            hipLaunchKernelGGL((k_sketch_tiles<1, 0>), dim3((u32)n_med), dim3(SK_THREADS), 0, ctx->stream, M);
+            hipLaunchKernelGGL((k_sketch_tiles<1, 0>), dim3((u32)(n_med < 2048 ? n_med : 2048)), dim3(SK_THREADS), 0, ctx->stream, M);
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
         }
@@ -1397,7 +1460,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             SK_CHECK(ks_alloc(ctx, &slab64, (size_t)(grid * stride * 3)));
             SK_CHECK(ks_alloc(ctx, &slab32, (size_t)(grid * stride * 4)));
             sk_long_args L;
-            L.a = A; L.long_ids = long_ids; L.n_long = n_cls; L.max_len = real_max;
+            L.a = A; L.long_ids = long_ids; L.n_long = n_cls; L.long_cap = (u32)n_long; L.max_len = real_max;
             L.slab_keys = slab64; L.slab_tmp = slab64 + grid * stride; L.slab_sorted = slab64 + 2 * grid * stride;
             L.slab_cnt = slab32; L.slab_ord = slab32 + grid * stride; L.slab_flag = slab32 + 2 * grid * stride;
             L.slab_ab = slab32 + 3 * grid * stride;
@@ -1452,14 +1515,16 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             if (n_med > 0) {
                 ks_timer_begin(ctx, "place_long");
                 // medium runs: copy only (their tiles emitted their own postings)
-                hipLaunchKernelGGL(k_place_long, dim3((u32)n_med), dim3(256), 0, ctx->stream, (const u32 *)med_ids, d_offs,
+                hipLaunchKernelGGL(k_place_long, dim3((u32)(n_med < 1024 ? n_med : 1024)), dim3(256), 0, ctx->stream, (const u32 *)med_ids,
+                                   (const u32 *)n_cls, (u32)n_med, d_offs,
                                    (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds, out_cap,
                                    (u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u64)0, 0u, 0u, 0u, ticket);
                 ks_timer_end(ctx);
             }
             if (n_long > 0) {
                 ks_timer_begin(ctx, "place_long");
-                hipLaunchKernelGGL(k_place_long, dim3((u32)n_long), dim3(256), 0, ctx->stream, (const u32 *)long_ids, d_offs,
+                hipLaunchKernelGGL(k_place_long, dim3((u32)(n_long < 1024 ? n_long : 1024)), dim3(256), 0, ctx->stream, (const u32 *)long_ids,
+                                   (const u32 *)(n_cls + 1), (u32)n_long, d_offs,
                                    (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds, out_cap,
                                    A.part_keys, A.part_vals, A.part_cursor, A.part_cap, A.part_K, A.part_mask, A.part_sub_shift, ticket);
                 ks_timer_end(ctx);
@@ -1468,12 +1533,21 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             // total + look-back error flag to the host
             SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, S->d_offsets + n_seqs, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
             SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin + 1, ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+            if (planned) SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin + 4, d_stats, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
             SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
             u32 &status_w = ((u32 *)(ctx->h_pin + 1))[1];
             if (attempt == 0 && !A.use_ticket && getenv("KS_DEBUG_FORCE_TICKET_RETRY")) status_w |= 1u; // exercises the repeat
             if (!(status_w & 1u) || A.use_ticket) break;
         }
         S->n_hashes = ctx->h_pin[0];
+        if (planned) {
+            S->n_windows = ctx->h_pin[4];
+            if (ctx->h_pin[5] > (u64)max_seq_len) { // the plan was made for shorter sequences: nothing of this launch can be trusted
+                st = ks_fail(ctx, KS_ERR_INVALID_ARG, "max_seq_len = %u, but the batch holds a sequence of %llu residues", max_seq_len,
+                             (unsigned long long)ctx->h_pin[5]);
+                goto done;
+            }
+        }
         {
             const u32 status = ((u32 *)(ctx->h_pin + 1))[1];
             if (status & 1u) { st = ks_fail(ctx, KS_ERR_HIP, "sketch: tile look-back timed out"); goto done; }
@@ -1507,14 +1581,13 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     KS_TRY(ks_check_params(ctx, p));
     if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
     if (((uintptr_t)d_res & 15) != 0) return ks_fail(ctx, KS_ERR_INVALID_ARG, "d_residues must be 16-byte aligned");
-    (void)max_seq_len; // hint only: the real maximum is measured on the device
     KS_HIP(ctx, hipSetDevice(ctx->device));
     // economies first (compacting tiles, outputs sized by the expected kept count); a batch that defeats one — repeats
     // whose hash falls under the threshold — is repeated without it (at most twice; the last variant always fits)
     int variant = 1;
     for (int round = 0; round < 3; round++) {
         int redo = 0;
-        const int st = sketch_attempt(ctx, d_res, d_offs, n_seqs, n_res, p, part_pbits, variant, &redo, out);
+        const int st = sketch_attempt(ctx, d_res, d_offs, n_seqs, n_res, max_seq_len, p, part_pbits, variant, &redo, out);
         if (st != KS_OK || !redo) return st;
         if (redo == 1) { variant &= ~1; ctx->sketch_compact_fallbacks++; }
         else { variant |= 2; ctx->sketch_cap_fallbacks++; }

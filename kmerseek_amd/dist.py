@@ -80,7 +80,8 @@ def broadcast_batch(residues: Optional[np.ndarray], offsets: Optional[np.ndarray
     return t_res, t_off
 
 
-def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=None, sharded: str = "queries"):
+def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=None, sharded: str = "queries",
+                           order: str = "qid"):
     """Concatenate every rank's COO hit list on the device: counts are exchanged first, then ONE padded
     ``all_gather_into_tensor`` moves the rows (RCCL over xGMI with backend "nccl"; gloo on CPU tensors in the tests).
 
@@ -88,7 +89,10 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
               (``ks_hits_copy_to_device``, ids shifted to global numbering by the copy kernel; no host round trip) —
               or a numpy 4-tuple of host columns (CPU tensors / gloo).
     sharded : "queries" — ranks own ascending qid ranges, so the concatenation in rank order already IS (qid, tid) order;
-              "index"   — ranks own ascending tid ranges: one stable device sort on qid restores (qid, tid) order.
+              "index"   — ranks own ascending tid ranges: the concatenation is ordered by (shard, qid, tid).
+    order   : "qid" (default) — for an index-sharded gather one stable device sort on qid restores global (qid, tid) order;
+              "shard" — leave the rank-major concatenation as it is (every block (qid, tid)-ordered; what BASELINE configs[4]
+              asks for: "all-gather of per-shard hit lists").
     Returns (qid i32, tid i32, intersect i32, n_weighted i64) torch tensors on `device`, identical on every rank."""
     import torch
     dist = _dist()
@@ -104,9 +108,11 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
         allc = torch.zeros(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allc, mine)
         counts = [int(c) for c in allc.tolist()]
-    cap = (max(max(counts), 1) + 63) // 64 * 64  # even: the i64 column of a block stays 8-byte aligned
-    # one block per rank, SoA: qid[cap] | tid[cap] | intersect[cap] | n_weighted[cap] (as 2 x i32 each)
-    send = torch.empty(5 * cap, dtype=torch.int32, device=dev)
+    # one block per rank, SoA: qid[cap] | tid[cap] | intersect[cap] | n_weighted[cap] (as 2 x i32 each); with one rank
+    # the block is exact, so its columns are the result (no second pass)
+    cap = n_local if world == 1 else (max(max(counts), 1) + 63) // 64 * 64
+    cap += cap & 1  # even: the i64 column of a block stays 8-byte aligned
+    send = torch.empty(max(5 * cap, 2), dtype=torch.int32, device=dev)
     if n_local:
         if on_device:
             base = send.data_ptr()
@@ -119,20 +125,19 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
             send[cap:cap + n_local] = torch.from_numpy((tid.astype(np.int64) + tid_base).astype(np.int32)).to(dev)
             send[2 * cap:2 * cap + n_local] = torch.from_numpy(isect.astype(np.int32)).to(dev)
             send[3 * cap:5 * cap].view(torch.int64)[:n_local] = torch.from_numpy(nw.astype(np.int64)).to(dev)
-    if world > 1:
-        recv = torch.empty(world * 5 * cap, dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(recv, send)
-    else:
-        recv = send
-    cols = [[], [], [], []]
-    for r, c in enumerate(counts):
-        blk = recv[r * 5 * cap:(r + 1) * 5 * cap]
-        cols[0].append(blk[0:c]); cols[1].append(blk[cap:cap + c]); cols[2].append(blk[2 * cap:2 * cap + c])
-        cols[3].append(blk[3 * cap:5 * cap].view(torch.int64)[:c])
-    qid, tid, isect, nw = (torch.cat(c) for c in cols)
-    if sharded == "index" and world > 1 and qid.numel():
-        order = torch.sort(qid, stable=True).indices  # inside one qid, rank order already is tid order
-        qid, tid, isect, nw = qid[order], tid[order], isect[order], nw[order]
+
+    def columns(blk, c):
+        return blk[0:c], blk[cap:cap + c], blk[2 * cap:2 * cap + c], blk[3 * cap:5 * cap].view(torch.int64)[:c]
+
+    if world == 1:
+        return columns(send, n_local)
+    recv = torch.empty(world * 5 * cap, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    cols = list(zip(*[columns(recv[r * 5 * cap:(r + 1) * 5 * cap], c) for r, c in enumerate(counts)]))
+    qid, tid, isect, nw = (torch.cat(c) for c in cols)  # one pass: the blocks are padded to the largest shard
+    if sharded == "index" and order == "qid" and qid.numel():
+        idx = torch.sort(qid, stable=True).indices  # inside one qid, rank order already is tid order
+        qid, tid, isect, nw = qid[idx], tid[idx], isect[idx], nw[idx]
     return qid, tid, isect, nw
 
 

@@ -535,3 +535,30 @@ def test_sketch_repeats_with_ticket_ids_when_a_lookback_gives_up(monkeypatch):
             assert np.array_equal(g, w)
     finally:
         ctx.close()
+
+
+def test_max_seq_len_plan_equals_measured_plan(ctx):
+    """ks_sketch_batch_device with an upper bound on the sequence length plans its launches on the host (one sync per
+    call); without it the batch is measured first.  Same sketches either way, for proteome-like, peptide and long-tailed
+    batches; a bound that is too small is refused."""
+    rng = np.random.default_rng(17)
+    batches = [synth.proteome(3000, stream=71), synth.proteome(3000, stream=72, hi=9000)]
+    lens = rng.integers(8, 60, 5000).astype(np.uint64)
+    offs = np.zeros(len(lens) + 1, np.uint64); np.cumsum(lens, out=offs[1:])
+    batches.append((rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8), int(offs[-1])).astype(np.uint8), offs))
+    for res, offs in batches:
+        real = int((offs[1:] - offs[:-1]).max())
+        d_res, d_off = ctx.to_device(res), ctx.to_device(offs)
+        for k, scaled, mol in ((10, 1, "protein"), (16, 5, "dayhoff")):
+            want = oracle.sketch_batch(res, offs, k, scaled, mol, n_threads=8)
+            for hint in (0, real, real + 1000, 40000):
+                S = ctx.sketch_batch_device(d_res.ptr, d_off.ptr, len(offs) - 1, len(res), k, scaled, mol, max_seq_len=hint)
+                assert S.n_windows == int(np.maximum((offs[1:] - offs[:-1]).astype(np.int64) - k + 1, 0).sum())
+                for g, w in zip(S.to_host(), want):
+                    assert np.array_equal(g, w), (k, scaled, mol, hint)
+                S.free()
+            if real > 1:
+                with pytest.raises(ks.KmerseekError) as e:
+                    ctx.sketch_batch_device(d_res.ptr, d_off.ptr, len(offs) - 1, len(res), k, scaled, mol, max_seq_len=real - 1)
+                assert "max_seq_len" in str(e.value)
+        d_res.free(); d_off.free()
