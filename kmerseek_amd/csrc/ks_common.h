@@ -205,6 +205,10 @@ int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, c
 // index build in three passes (two partition passes + in-LDS bucket sort); *overflowed = 1: use the LSD sort instead
 int ks_index_sort_partitioned(ks_ctx *ctx, const u64 *keys_in, const u64 *vals_in, u64 n, u64 max_hash, u64 *okeys, u32 *otids,
                               u32 *oabunds, u32 *d_max_abund, int *overflowed);
+// Match-list sort in three moves whatever the key width (ks_msd.hip): two exact MSD partition levels of 8 bits + in-LDS sort of the
+// 65,536 buckets.  Sorts `ka` in place on key bits [lo_bit, lo_bit + nbits); kb = scratch.  *done = 0: not applicable (small list /
+// narrow key / KS_DEBUG_PAIRS_LSD), the caller takes the LSD passes.
+int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbits, int *done);
 int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_in, u64 *ka, u64 *va, u64 *kb, u64 *vb,
                       u64 n, const int *shifts, int n_shifts, u64 **keys_out, u64 **vals_out);
 

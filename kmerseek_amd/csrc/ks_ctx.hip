@@ -260,7 +260,7 @@ static void timer_resolve(ks_ctx *ctx) {
 // the kernels that move the bulk of the bytes: the only ones bracketed in mode 2
 static bool timer_is_major(const char *name) {
     static const char *const major[] = {"sketch_tiles", "bucket_scatter", "radix_scatter.qpart", "radix_hist.qpart", "join_buckets",
-                                        "radix_scatter.index", "sketch_long", "sketch_medium"};
+                                        "radix_scatter.index", "sketch_long", "sketch_medium", "msd_scatter", "msd_local"};
     for (const char *m : major)
         if (!strcmp(name, m)) return true;
     return false;

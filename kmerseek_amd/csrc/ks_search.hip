@@ -568,8 +568,12 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         {
             int shifts[8], ns = 0;
             for (int sh = 0; sh < tbits + qbits; sh += 8) shifts[ns++] = abits + sh;
-            // the match list (pk0, pv0) is scratch from here on: ping-pong with (pk1, pv1)
-            if (packed) SE_CHECK(ks_radix_sort_keys(ctx, KS_SORT_PAIRS, pk0, pk0, pk1, n_pairs, shifts, ns, &pk));
+            // the match list (pk0, pv0) is scratch from here on: ping-pong with (pk1, pv1).  Packed records: three moves
+            // (two exact MSD partition levels + in-LDS bucket sort, ks_msd.hip) instead of one per 8 key bits
+            int msd = 0;
+            if (packed) SE_CHECK(ks_sort_pairs_msd(ctx, pk0, pk1, n_pairs, abits, tbits + qbits, &msd));
+            if (msd) pk = pk0;
+            else if (packed) SE_CHECK(ks_radix_sort_keys(ctx, KS_SORT_PAIRS, pk0, pk0, pk1, n_pairs, shifts, ns, &pk));
             else SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_PAIRS, pk0, pv0, pk0, pv0, pk1, pv1, n_pairs, shifts, ns, &pk, &pv));
         }
         // run-length reduce

@@ -562,3 +562,41 @@ def test_max_seq_len_plan_equals_measured_plan(ctx):
                     ctx.sketch_batch_device(d_res.ptr, d_off.ptr, len(offs) - 1, len(res), k, scaled, mol, max_seq_len=real - 1)
                 assert "max_seq_len" in str(e.value)
         d_res.free(); d_off.free()
+
+
+def test_match_sort_msd_equals_lsd_and_survives_skew(ctx):
+    """The match list is sorted by two exact MSD partition levels + in-LDS bucket sorts (ks_msd.hip); the LSD passes stay
+    as the path for short lists / narrow keys.  Same hits either way — also when buckets are forced out of LDS into the
+    serial global-memory path, and on a skewed list (one query that matches every target, duplicated targets)."""
+    t_res, t_off = synth.proteome(6000, stream=301)
+    q_res, q_off = synth.queries(5000, t_res, t_off, stream=302, frac_related=0.6)
+    # skew: the first 400 targets repeated 6x (heavy (qid, tid) groups), and one query made of pieces of many targets
+    rep = [bytes(t_res[int(t_off[i]):int(t_off[i + 1])]) for i in range(400)]
+    seqs_t = [bytes(t_res[int(t_off[i]):int(t_off[i + 1])]) for i in range(6000)] + rep * 6
+    chim = b"".join(bytes(t_res[int(t_off[i]):int(t_off[i]) + 40]) for i in range(0, 6000, 3))
+    seqs_q = [bytes(q_res[int(q_off[i]):int(q_off[i + 1])]) for i in range(5000)] + [chim]
+    T = ctx.sketch_batch(*ks.pack(seqs_t), 7, 1, "protein")
+    Q = ctx.sketch_batch(*ks.pack(seqs_q), 7, 1, "protein")
+    ix = ctx.index_build(T)
+    base = ctx.search(ix, Q)
+    assert base.n_pair_instances > 200_000  # long enough for the MSD path
+    want = base.to_host()
+    key = want[0].astype(np.uint64) << np.uint64(32) | want[1].astype(np.uint64)
+    assert np.all(key[1:] > key[:-1]) and int(want[2].sum()) == base.n_pair_instances
+    for env in ({"KS_DEBUG_PAIRS_LSD": "1"}, {"KS_DEBUG_MSD_LDS_CAP": "64"}, {"KS_DEBUG_MSD_LDS_CAP": "700"},
+                {"KS_DEBUG_UNPACKED_PAIRS": "1"}):
+        os.environ.update(env)
+        try:
+            got = ctx.search(ix, Q).to_host()
+        finally:
+            for k_ in env:
+                del os.environ[k_]
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), env
+    # and against the oracle on a query sample that includes the chimera
+    qo, qm, _ = Q.to_host()
+    to, tm, ta = T.to_host()
+    for qi in (0, 17, 4999, 5000):
+        w = oracle.manysearch(np.array([0, qo[qi + 1] - qo[qi]], np.uint64), qm[int(qo[qi]):int(qo[qi + 1])], to, tm, ta, n_threads=8)
+        sel = want[0] == qi
+        assert np.array_equal(want[1][sel], w[1]) and np.array_equal(want[2][sel], w[2]) and np.array_equal(want[3][sel], w[3])
