@@ -238,6 +238,7 @@ def run_queries_sharded(args, env, ks, synth, ksd):
         torch.cuda.synchronize(env.dev)
         aux["kmers_sketched_per_s_device_resident"] = 3 * q_windows / (time.perf_counter() - c0)
         # end to end from host buffers: H2D of residues + offsets, sketch, search, D2H of the hit rows (and of the CSR)
+        ctx.sketch_batch(*ks.pack([b"ACDEFGHIKLMNPQRSTVWY" * 40] * 20000), k, scaled, mol).to_host()  # staging buffers exist
         qh_res = q_res[:n_q_res].cpu().numpy()
         qh_off = q_off.cpu().numpy().view(np.uint64)
         c0 = time.perf_counter()
@@ -245,10 +246,19 @@ def run_queries_sharded(args, env, ks, synth, ksd):
         H = ctx.search(index, Q)
         rows = H.to_host()
         c1 = time.perf_counter()
-        csr = Q.to_host()
+        csr = Q.to_host()                      # pageable numpy arrays: staged through pinned buffers by host threads
+        c2p = c2 = time.perf_counter()
+        # pinned arrays (ks_host_alloc), allocated beforehand as a caller that streams batches would: one DMA each
+        pins = (ctx.pinned_empty(len(csr[0]), np.uint64), ctx.pinned_empty(len(csr[1]), np.uint64), ctx.pinned_empty(len(csr[2]), np.uint32))
         c2 = time.perf_counter()
+        ctx._check(ctx._L.ks_sketches_copy_to_host(ctx._h, Q._h, *[p_.ctypes.data_as(ks._lib.C.c_void_p) for p_ in pins]))
+        c3 = time.perf_counter()
+        del pins
         aux["end_to_end_host_buffers"] = {
-            "kmers_per_s_hits_to_host": q_windows / (c1 - c0), "kmers_per_s_hits_and_sketches_to_host": q_windows / (c2 - c0),
+            "kmers_per_s_hits_to_host": q_windows / (c1 - c0), "kmers_per_s_hits_and_sketches_to_host": q_windows / (c2p - c0),
+            "kmers_per_s_hits_and_sketches_to_pinned_host": q_windows / (c1 - c0 + c3 - c2),
+            "sketches_d2h_gb_per_s_pageable": sum(a.nbytes for a in csr) / (c2p - c1) / 1e9,
+            "sketches_d2h_gb_per_s_pinned": sum(a.nbytes for a in csr) / (c3 - c2) / 1e9,
             "h2d_bytes": int(qh_res.nbytes + qh_off.nbytes), "d2h_hit_bytes": int(sum(a.nbytes for a in rows)),
             "d2h_sketch_bytes": int(sum(a.nbytes for a in csr)),
             "note": "single call from pageable host arrays; never the headline value"}
@@ -259,6 +269,7 @@ def run_queries_sharded(args, env, ks, synth, ksd):
             r = ctx.device_rates()
             aux["device"] = {"name": torch.cuda.get_device_name(env.dev), "hbm_nominal_gb_per_s_from_properties": r["nominal_gb_per_s"],
                              "d2d_copy_gb_per_s_measured": r["copy_gb_per_s"], "u64_gmul_per_s_measured": r["u64_gmul_per_s"]}
+            aux["device"].update(ctx.gather_rates())  # ceiling of a table-lookup hash for the hp alphabet
         except Exception as e:  # a side line must not cost the headline
             aux["device"] = {"error": str(e)}
 
@@ -375,7 +386,7 @@ def load_traffic():
 def kernel_sources_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "kmerseek_amd", "csrc")
-    for f in ("ks_sketch.hip", "ks_search.hip", "ks_prims.hip", "ks_device.h"):
+    for f in ("ks_sketch.hip", "ks_search.hip", "ks_prims.hip", "ks_msd.hip", "ks_device.h"):
         p = os.path.join(d, f)
         if os.path.exists(p):
             h.update(open(p, "rb").read())

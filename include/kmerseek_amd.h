@@ -106,6 +106,12 @@ int ks_dev_free(ks_ctx *ctx, void *ptr);
 int ks_dev_upload(ks_ctx *ctx, void *dst_device, const void *src_host, uint64_t bytes);
 int ks_dev_download(ks_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
 
+/* Pinned (page-locked) host memory.  Host buffers handed to this library are copied in one DMA at link rate when they are
+ * pinned (ks_host_alloc, hipHostMalloc, hipHostRegister); pageable ones go through the context's double-buffered pinned
+ * staging with a few host copy threads.  Callers that want sketches / k-mer tables back should receive them in pinned arrays. */
+int ks_host_alloc(ks_ctx *ctx, uint64_t bytes, void **out);
+int ks_host_free(ks_ctx *ctx, void *ptr);
+
 /* ---- host-side pre-step ------------------------------------------------------------------ */
 
 typedef struct ks_residue_error {
@@ -250,6 +256,9 @@ int ks_timing_get(ks_ctx *ctx, ks_kernel_time *rows, uint32_t cap, uint32_t *n);
  *   copy_gb_per_s - device-to-device hipMemcpy rate, bytes read + bytes written per second / 1e9,
  *   nominal_gb_per_s - memoryClockRate x memoryBusWidth of the device properties (DDR: x2) / 1e9. */
 int ks_bench_device_rates(ks_ctx *ctx, double *gmul_per_s, double *copy_gb_per_s, double *nominal_gb_per_s);
+/* random 8-byte gathers per second from a 134 MB table ([0]) and from a 2 MB table ([1]): the ceiling of a table-lookup hash
+ * for the two-letter hp alphabet (see DESIGN.md for why the multiplies win) */
+int ks_bench_gather_rates(ks_ctx *ctx, double gathers_per_s[2]);
 
 #ifdef __cplusplus
 }

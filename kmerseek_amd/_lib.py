@@ -60,6 +60,8 @@ SIGNATURES = {
     "ks_ctx_stream": (_vp, [_vp]),
     "ks_ctx_synchronize": (C.c_int, [_vp]),
     "ks_ctx_sketch_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
+    "ks_host_alloc": (C.c_int, [_vp, C.c_uint64, _pp]),
+    "ks_host_free": (C.c_int, [_vp, _vp]),
     "ks_dev_malloc": (C.c_int, [_vp, C.c_uint64, _pp]),
     "ks_dev_free": (C.c_int, [_vp, _vp]),
     "ks_dev_upload": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
@@ -105,6 +107,7 @@ SIGNATURES = {
     "ks_timing_enable": (C.c_int, [_vp, C.c_int]),
     "ks_timing_reset": (C.c_int, [_vp]),
     "ks_timing_get": (C.c_int, [_vp, C.POINTER(ks_kernel_time), C.c_uint32, _u32p]),
+    "ks_bench_gather_rates": (C.c_int, [_vp, C.POINTER(C.c_double * 2)]),
     "ks_bench_device_rates": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libkmerseek_amd.so")
-SOURCES = ["ks_ctx.hip", "ks_prims.hip", "ks_msd.hip", "ks_sketch.hip", "ks_search.hip", "ks_api.hip", "ks_host.cpp", "ks_ingest.cpp", "ks_input.cpp"]
+SOURCES = ["ks_ctx.hip", "ks_prims.hip", "ks_msd.hip", "ks_copy.hip", "ks_sketch.hip", "ks_search.hip", "ks_api.hip", "ks_host.cpp", "ks_ingest.cpp", "ks_input.cpp"]
 HEADERS = ["ks_common.h", "ks_device.h", "ks_input.h", os.path.join("..", "..", "include", "kmerseek_amd.h"),
            os.path.join("..", "..", "include", "kmerseek_host.hpp"), os.path.join("..", "..", "include", "kmerseek_host_c.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

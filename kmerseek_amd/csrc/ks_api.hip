@@ -38,7 +38,7 @@ static int upload_batch(ks_ctx *ctx, const uint8_t *residues, const uint64_t *se
     KS_HIP(ctx, hipSetDevice(ctx->device));
     KS_TRY(ks_alloc(ctx, d_res, (size_t)total + 16));
     KS_TRY(ks_alloc(ctx, d_offs, (size_t)n_seqs + 1));
-    if (total) KS_HIP(ctx, hipMemcpyAsync(*d_res, residues, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    if (total) KS_TRY(ks_copy_h2d(ctx, *d_res, residues, (size_t)total));
     KS_HIP(ctx, hipMemcpyAsync(*d_offs, seq_offsets, ((size_t)n_seqs + 1) * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
     *n_res = total;
     *max_len = (u32)mx;
@@ -76,8 +76,8 @@ extern "C" int ks_sketches_copy_to_host(ks_ctx *ctx, const ks_sketches *s, uint6
     if (!ctx || !s) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     if (offsets) KS_HIP(ctx, hipMemcpyAsync(offsets, s->d_offsets, ((size_t)s->n_seqs + 1) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-    if (hashes && s->n_hashes) KS_HIP(ctx, hipMemcpyAsync(hashes, s->d_hashes, (size_t)s->n_hashes * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-    if (abunds && s->n_hashes) KS_HIP(ctx, hipMemcpyAsync(abunds, s->d_abunds, (size_t)s->n_hashes * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    if (hashes && s->n_hashes) KS_TRY(ks_copy_d2h(ctx, hashes, s->d_hashes, (size_t)s->n_hashes * sizeof(u64)));
+    if (abunds && s->n_hashes) KS_TRY(ks_copy_d2h(ctx, abunds, s->d_abunds, (size_t)s->n_hashes * sizeof(u32)));
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
 }
@@ -193,9 +193,9 @@ extern "C" int ks_kmerpos_copy_to_host(ks_ctx *ctx, const ks_kmerpos *p, uint32_
     if (!ctx || !p) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     if (p->n) {
-        if (seq) KS_HIP(ctx, hipMemcpyAsync(seq, p->d_seq, (size_t)p->n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-        if (start) KS_HIP(ctx, hipMemcpyAsync(start, p->d_start, (size_t)p->n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-        if (hash) KS_HIP(ctx, hipMemcpyAsync(hash, p->d_hash, (size_t)p->n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        if (seq) KS_TRY(ks_copy_d2h(ctx, seq, p->d_seq, (size_t)p->n * sizeof(u32)));
+        if (start) KS_TRY(ks_copy_d2h(ctx, start, p->d_start, (size_t)p->n * sizeof(u32)));
+        if (hash) KS_TRY(ks_copy_d2h(ctx, hash, p->d_hash, (size_t)p->n * sizeof(u64)));
     }
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
@@ -240,10 +240,10 @@ extern "C" int ks_hits_copy_to_host(ks_ctx *ctx, const ks_hits *h, uint32_t *qid
     KS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)h->n_hits;
     if (n) {
-        if (qid) KS_HIP(ctx, hipMemcpyAsync(qid, h->d_qid, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-        if (tid) KS_HIP(ctx, hipMemcpyAsync(tid, h->d_tid, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-        if (intersect) KS_HIP(ctx, hipMemcpyAsync(intersect, h->d_isect, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-        if (n_weighted) KS_HIP(ctx, hipMemcpyAsync(n_weighted, h->d_nw, n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        if (qid) KS_TRY(ks_copy_d2h(ctx, qid, h->d_qid, n * sizeof(u32)));
+        if (tid) KS_TRY(ks_copy_d2h(ctx, tid, h->d_tid, n * sizeof(u32)));
+        if (intersect) KS_TRY(ks_copy_d2h(ctx, intersect, h->d_isect, n * sizeof(u32)));
+        if (n_weighted) KS_TRY(ks_copy_d2h(ctx, n_weighted, h->d_nw, n * sizeof(u64)));
     }
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;

@@ -33,8 +33,11 @@ struct ks_timer_slot {
     int name_id;
 };
 
+struct ks_copy_engine; // ks_copy.hip: pinned staging + host copy threads for pageable host buffers
+
 struct ks_ctx {
     int device = 0;
+    ks_copy_engine *copy = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int n_cus = 256;
@@ -229,3 +232,8 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
 int ks_union_impl(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out);
 
 int ks_check_params(ks_ctx *ctx, const ks_params *p);
+
+// ---- boundary copies (ks_copy.hip): one DMA for pinned host memory, double-buffered pinned staging + copy threads otherwise
+int ks_copy_h2d(ks_ctx *ctx, void *dst_device, const void *src_host, size_t bytes); // enqueued; complete for pageable sources
+int ks_copy_d2h(ks_ctx *ctx, void *dst_host, const void *src_device, size_t bytes); // returns when dst holds the data
+void ks_copy_engine_destroy(ks_ctx *ctx);

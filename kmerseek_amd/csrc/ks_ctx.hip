@@ -126,6 +126,7 @@ extern "C" void ks_ctx_destroy(ks_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ks_copy_engine_destroy(ctx);
     for (auto &t : ctx->t_pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto &t : ctx->t_free) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     for (auto &b : ctx->pool) (void)hipFree(b.ptr);
@@ -178,13 +179,15 @@ extern "C" int ks_dev_free(ks_ctx *ctx, void *ptr) {
 }
 extern "C" int ks_dev_upload(ks_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     if (!ctx || (bytes && (!dst || !src))) return KS_ERR_INVALID_ARG;
-    if (bytes) KS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    KS_TRY(ks_copy_h2d(ctx, dst, src, (size_t)bytes));
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
 }
 extern "C" int ks_dev_download(ks_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     if (!ctx || (bytes && (!dst || !src))) return KS_ERR_INVALID_ARG;
-    if (bytes) KS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    KS_TRY(ks_copy_d2h(ctx, dst, src, (size_t)bytes));
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
 }
@@ -376,6 +379,51 @@ extern "C" int ks_bench_device_rates(ks_ctx *ctx, double *gmul_per_s, double *co
         if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "hipGetDeviceProperties failed");
         else *nominal_gb_per_s = 2.0 * (double)prop.memoryClockRate * 1e3 * ((double)prop.memoryBusWidth / 8.0) / 1e9;
     }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return st;
+}
+
+// ---- random-gather rates (SURVEY §7's "small-alphabet table path" for hp: a rolling 24-bit window index into a table of
+// precomputed murmur hashes, 2^24 x 8 B = 134 MB, or into a 2^24-bit keep-bitmap, 2 MB).  The probe answers whether a
+// gather can replace the ten 64-bit multiplies of the hash: it cannot.
+__global__ __launch_bounds__(256) void k_bench_gather(const u64 *table, u64 mask, u32 iters, u64 *out) {
+    u64 x = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 0x9e3779b97f4a7c15ULL + 1, acc = 0;
+    for (u32 i = 0; i < iters; i++) { // four independent gathers per round: latency hidden by ILP + occupancy
+        u64 a = x * 0xbf58476d1ce4e5b9ULL, b = a ^ (a >> 29), c = b * 0x94d049bb133111ebULL, d = c ^ (c >> 31);
+        acc += table[a >> 40 & mask] + table[b >> 13 & mask] + table[c >> 37 & mask] + table[d >> 7 & mask];
+        x = d + i;
+    }
+    out[(u64)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+// gathers_per_s[0]: random 8-byte gathers from a 134 MB table; [1]: from a 2 MB table (fits one XCD's L2)
+extern "C" int ks_bench_gather_rates(ks_ctx *ctx, double *gathers_per_s) {
+    if (!ctx || !gathers_per_s) return KS_ERR_INVALID_ARG;
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    KS_HIP(ctx, hipEventCreate(&e0));
+    KS_HIP(ctx, hipEventCreate(&e1));
+    const u32 blocks = 256 * 24, iters = 256;
+    u64 *table = nullptr, *out = nullptr;
+    int st = ks_alloc(ctx, &table, (size_t)1 << 24);
+    if (st == KS_OK) st = ks_alloc(ctx, &out, (size_t)blocks * 256);
+    if (st == KS_OK) {
+        (void)hipMemsetAsync(table, 1, ((size_t)1 << 24) * sizeof(u64), ctx->stream);
+        const u64 masks[2] = {(1ULL << 24) - 1, (1ULL << 18) - 1};
+        for (int v = 0; v < 2 && st == KS_OK; v++) {
+            float ms = 0;
+            hipLaunchKernelGGL(k_bench_gather, dim3(blocks), dim3(256), 0, ctx->stream, (const u64 *)table, masks[v], 8u, out); // warm-up
+            (void)hipEventRecord(e0, ctx->stream);
+            hipLaunchKernelGGL(k_bench_gather, dim3(blocks), dim3(256), 0, ctx->stream, (const u64 *)table, masks[v], iters, out);
+            (void)hipEventRecord(e1, ctx->stream);
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                st = ks_fail(ctx, KS_ERR_HIP, "gather micro-benchmark failed");
+            else
+                gathers_per_s[v] = (double)blocks * 256 * iters * 4 / (ms * 1e-3);
+        }
+    }
+    ks_pool_free(ctx, table); ks_pool_free(ctx, out);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return st;

@@ -16,6 +16,7 @@
 // measured against).  Nothing here computes a hash on the CPU.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -84,7 +85,7 @@ struct Slot { // one batch in flight: pinned host staging + its device copy
     uint64_t *h_offs = nullptr, *d_offs = nullptr;
     size_t res_cap = 0, offs_cap = 0;
     size_t n_res = 0;
-    uint32_t n_seqs = 0;
+    uint32_t n_seqs = 0, max_len = 0;
     std::vector<std::string> names;
     // pinned landing zone of the batch's sketches (kept hashes <= windows <= residues)
     uint64_t *h_coffs = nullptr, *h_hash = nullptr;
@@ -354,6 +355,9 @@ class Ingest {
         }
         s.n_res = s.h_offs[n];
         s.n_seqs = (uint32_t)n;
+        uint64_t mx = 0; // upper bound on the sequence length: the device call then plans its launches without a round trip
+        for (size_t i = 0; i < n; i++) mx = std::max<uint64_t>(mx, s.h_offs[i + 1] - s.h_offs[i]);
+        s.max_len = mx > 0xfffffff0ULL ? 0u : (uint32_t)mx;
         s.names = std::move(b.names);
         records_done_ += n;
         out_->t_pack += secs(t0, clk::now());
@@ -376,7 +380,7 @@ class Ingest {
     bool sketch(Slot &s) {
         const auto t0 = clk::now();
         ks_sketches *S = nullptr;
-        int st = ks_sketch_batch_device(ctx_, s.d_res, s.d_offs, s.n_seqs, s.n_res, 0, &params_, &S);
+        int st = ks_sketch_batch_device(ctx_, s.d_res, s.d_offs, s.n_seqs, s.n_res, s.max_len, &params_, &S);
         if (st != KS_OK) { fail_.raise(13, std::string("ks_sketch_batch_device: ") + ks_last_error(ctx_)); return false; }
         s.n_hashes = ks_sketches_n_hashes(S);
         s.n_windows = ks_sketches_n_windows(S);

@@ -128,6 +128,18 @@ class Context:
         self._check(self._L.ks_dev_upload(self._h, p, _ptr(a), a.nbytes))
         return buf
 
+    def pinned_empty(self, n: int, dtype) -> np.ndarray:
+        """Uninitialised numpy array of n items in pinned host memory (ks_host_alloc): copies between such an array and the
+        device run as one DMA at link rate, where a pageable array is staged through pinned buffers by host threads.
+        The memory is released when the array (and every view of it) is garbage-collected."""
+        dt = np.dtype(dtype)
+        nbytes = max(int(n) * dt.itemsize, 1)
+        p = C.c_void_p()
+        self._check(self._L.ks_host_alloc(self._h, nbytes, C.byref(p)))
+        buf = (C.c_char * nbytes).from_address(p.value)
+        buf._owner = _PinnedBlock(self, p)  # the ctypes view is the array's base: it keeps the block alive
+        return np.frombuffer(buf, dtype=dt, count=int(n))
+
     def pool_stats(self) -> Dict[str, int]:
         v = [C.c_uint64(0) for _ in range(4)]
         self._check(self._L.ks_ctx_pool_stats(self._h, *[C.byref(x) for x in v]))
@@ -237,12 +249,31 @@ class Context:
         self._check(self._L.ks_bench_device_rates(self._h, *[C.byref(x) for x in v]))
         return {"u64_gmul_per_s": v[0].value, "copy_gb_per_s": v[1].value, "nominal_gb_per_s": v[2].value}
 
+    def gather_rates(self) -> Dict[str, float]:
+        """Random 8-byte gathers per second from a 134 MB and from a 2 MB table (the ceiling of a table-lookup hash for hp)."""
+        v = (C.c_double * 2)()
+        self._check(self._L.ks_bench_gather_rates(self._h, C.byref(v)))
+        return {"gathers_per_s_134mb": v[0], "gathers_per_s_2mb": v[1]}
+
     def timing(self) -> Dict[str, Tuple[int, float]]:
         """{kernel name: (launches, total ms)} from HIP events on the context's stream."""
         n = C.c_uint32(0)
         rows = (_lib.ks_kernel_time * 64)()
         self._check(self._L.ks_timing_get(self._h, rows, 64, C.byref(n)))
         return {rows[i].name.decode(): (int(rows[i].launches), float(rows[i].total_ms)) for i in range(min(n.value, 64))}
+
+
+class _PinnedBlock:
+    def __init__(self, ctx: "Context", ptr):
+        self._ctx, self._p = ctx, ptr
+
+    def __del__(self):
+        try:
+            if self._p is not None and self._ctx._h:
+                self._ctx._L.ks_host_free(self._ctx._h, self._p)
+        except Exception:
+            pass
+        self._p = None
 
 
 class DeviceBuffer:
@@ -309,9 +340,15 @@ class Sketches(_Owned):
         self._ctx._check(self._ctx._L.ks_sketches_union(self._ctx._h, self._h, C.byref(out)))
         return Sketches(self._ctx, out)
 
-    def to_host(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    def to_host(self, pinned: bool = False) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(offsets u64[n+1], hashes u64, abunds u32) on the host.  pinned=True returns arrays in pinned memory
+        (Context.pinned_empty): one DMA at link rate instead of staged copies — what large sketch sets should use."""
         n, m = self.n_seqs, self.n_hashes
-        offs = np.zeros(n + 1, np.uint64); hashes = np.zeros(m, np.uint64); abunds = np.zeros(m, np.uint32)
+        if pinned:
+            offs = self._ctx.pinned_empty(n + 1, np.uint64); hashes = self._ctx.pinned_empty(m, np.uint64)
+            abunds = self._ctx.pinned_empty(m, np.uint32)
+        else:
+            offs = np.empty(n + 1, np.uint64); hashes = np.empty(m, np.uint64); abunds = np.empty(m, np.uint32)
         self._ctx._check(self._ctx._L.ks_sketches_copy_to_host(self._ctx._h, self._h, _ptr(offs), _ptr(hashes),
                                                                _ptr(abunds)))
         return offs, hashes, abunds

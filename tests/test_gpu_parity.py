@@ -600,3 +600,34 @@ def test_match_sort_msd_equals_lsd_and_survives_skew(ctx):
         w = oracle.manysearch(np.array([0, qo[qi + 1] - qo[qi]], np.uint64), qm[int(qo[qi]):int(qo[qi + 1])], to, tm, ta, n_threads=8)
         sel = want[0] == qi
         assert np.array_equal(want[1][sel], w[1]) and np.array_equal(want[2][sel], w[2]) and np.array_equal(want[3][sel], w[3])
+
+
+def test_boundary_copies_staged_pinned_and_plain_agree(ctx):
+    """Host <-> device copies of the boundary: pageable buffers go through double-buffered pinned staging with host copy
+    threads, pinned ones (Context.pinned_empty) in one DMA, KS_DEBUG_PLAIN_COPIES forces the runtime's own path.  Same bytes."""
+    res, offs = synth.proteome(60000, stream=77)          # 17 M residues up, ~200 MB of sketches back: several staging chunks
+    S = ctx.sketch_batch(res, offs, 10, 1, "protein")
+    a = S.to_host()
+    b = S.to_host(pinned=True)
+    os.environ["KS_DEBUG_PLAIN_COPIES"] = "1"
+    try:
+        c = S.to_host()
+        S2 = ctx.sketch_batch(res, offs, 10, 1, "protein")
+        d = S2.to_host()
+    finally:
+        del os.environ["KS_DEBUG_PLAIN_COPIES"]
+    assert a[1].nbytes > 64 << 20
+    for x, y, z, w in zip(a, b, c, d):
+        assert np.array_equal(x, y) and np.array_equal(x, z) and np.array_equal(x, w)
+    # pinned source for the upload path, odd sizes around the chunk size
+    for n in (1, (32 << 20) - 3, (32 << 20) + 1, (96 << 20) + 12345):
+        src = np.random.default_rng(n).integers(0, 255, n, dtype=np.uint8)
+        pin = ctx.pinned_empty(n, np.uint8)
+        pin[:] = src
+        for host in (src, pin):
+            dbuf = ctx.to_device(host)
+            back = np.empty(n, np.uint8)
+            ctx._check(ctx._L.ks_dev_download(ctx._h, back.ctypes.data_as(ks._lib.C.c_void_p), dbuf._p, n))
+            assert np.array_equal(back, src)
+            dbuf.free()
+    del b, pin
