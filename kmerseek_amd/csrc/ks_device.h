@@ -69,6 +69,14 @@ KS_DEV u32 ks_xcd_block() {
     return x * q + (x < rem ? x : rem) + (b >> 3);
 }
 
+// Decoupled look-back spins are bounded by TIME — the constant-rate wall clock (100 MHz on gfx950), read only every 1024
+// polls — not by an iteration count: a predecessor that is merely slow (a shared GPU, several ranks rehearsing on one
+// device) must not look like a protocol violation.  ~2 s.
+#define KS_SPIN_TICKS 200000000LL
+KS_DEV bool ks_spin_expired(long long t0, u32 &polls) {
+    return ((++polls) & 1023u) == 0 && wall_clock64() - t0 > KS_SPIN_TICKS;
+}
+
 // ---- wave / block exclusive scans (u32) ----
 KS_DEV u32 ks_wave_incl_scan(u32 v) {
     const u32 lane = threadIdx.x & 63;

@@ -114,7 +114,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_small(T *data, u64 n) {
 #define SCAN_FLAG_AGG 1ULL
 #define SCAN_FLAG_PRE 2ULL
 #define SCAN_VAL_BITS 38
-#define SCAN_SPIN_MAX (1u << 22)
 KS_DEV unsigned long long scan_word(u64 flag, u32 gtile, u64 value) {
     return (flag << 62) | ((u64)(gtile & 0xffffffu) << SCAN_VAL_BITS) | value;
 }
@@ -150,6 +149,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn *in, T
             i64 idx = (i64)tile - 1;
             bool done = false;
             u32 spins = 0;
+            const long long spin_t0 = wall_clock64();
             while (!done) {
                 const i64 mine = idx - (i64)tid;
                 u64 flag = SCAN_FLAG_PRE, val = 0; // before tile 0: inclusive prefix 0
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn *in, T
                         flag = w >> 62;
                         if (flag != 0 && ((w >> SCAN_VAL_BITS) & 0xffffffu) == want) { val = w & ((1ULL << SCAN_VAL_BITS) - 1ULL); break; }
                         flag = 0;
-                        if (++spins >= SCAN_SPIN_MAX) break;
+                        if (ks_spin_expired(spin_t0, spins)) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }

@@ -105,7 +105,6 @@ struct sk_args {
 #define SK_FLAG_AGG (1ULL << 62)
 #define SK_FLAG_PRE (2ULL << 62)
 #define SK_VAL_MASK ((1ULL << 62) - 1)
-#define SK_SPIN_MAX (1u << 22)
 
 // bucket multiplier: bucket = umulhi(h >> 32, mul) < n_windows for every kept h (h <= max_hash)
 KS_DEV u32 sk_bucket_mul(u32 nw, u32 sfix) {
@@ -542,10 +541,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                     rank_in_bucket(sb, c, o, h[i], p, eq, rep); // no queue room (tile nearly full): rank in place
                 }
             }
-            if (done) {
-                pa[i] = (eq << 16) | (p << 1) | rep; // eq <= 4096 windows of a tile
-                if (rep) atomicOr(&flagbits[p >> 5], 1u << (p & 31));
-            }
+            if (done) pa[i] = (eq << 16) | (p << 1) | rep; // eq <= 4096 windows of a tile
         }
     }
     __syncthreads();
@@ -559,7 +555,6 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             u32 p, eq, rep;
             rank_in_bucket(sb, c, o, tmp[sb + o], p, eq, rep);
             queue[e] = p | (rep << 12) | (eq << 13);
-            if (rep) atomicOr(&flagbits[p >> 5], 1u << (p & 31));
         }
     }
     __syncthreads();
@@ -571,21 +566,36 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             pa[i] = ((r >> 13) << 16) | ((r & 0xfffu) << 1) | ((r >> 12) & 1u);
         }
     }
-    __syncthreads();
+    // Does any hash of this tile repeat inside its sequence?  For protein k-mers almost never (the 1M-protein batch: a
+    // handful of tiles), and then every kept hash is its own representative with abundance 1 and its distinct rank IS its
+    // sorted position: the flag / bit-prefix machinery below is only run by tiles that need it (low-complexity sequences,
+    // the reduced alphabets).
+    bool dup = false;
+#pragma unroll
+    for (int i = 0; i < SK_E; i++) dup |= pa[i] != 0 && (pa[i] & 0xffff0001u) != 0x00010001u; // not (abundance 1, representative)
+    const bool any_dup = __syncthreads_or(dup);
 
     SK_STAMP_AT(5);
     // ---- phase 6: prefix over representative flags -> distinct rank
-    {
+    if (any_dup) { // (uniform)
+#pragma unroll
+        for (int i = 0; i < SK_E; i++)
+            if (pa[i] & 1u) {
+                const u32 p = (pa[i] >> 1) & 0xfffu;
+                atomicOr(&flagbits[p >> 5], 1u << (p & 31));
+            }
+        __syncthreads();
         u32 v = tid < SK_NFLAG ? (u32)__popc(flagbits[tid]) : 0;
         u32 total;
         u32 ex = ks_block_excl_scan(v, scan_smem, &total);
         if (tid < SK_NFLAG) flagpre[tid] = ex;
         if (tid == 0) flagpre[SK_NFLAG] = total;
+        __syncthreads();
     }
-    __syncthreads();
-    const u32 n_distinct = flagpre[SK_NFLAG];
+    const u32 n_distinct = any_dup ? flagpre[SK_NFLAG] : n_kept;
 
     auto drank = [&](u32 x) -> u32 { // representatives among sorted positions < x
+        if (!any_dup) return x < n_kept ? x : n_kept;
         return x >= SK_TILE ? n_distinct : flagpre[x >> 5] + (u32)__popc(flagbits[x >> 5] & ((1u << (x & 31)) - 1u));
     };
     u16 *abund_s = (u16 *)cnt; // abundance staging reuses the bucket-start words once they are dead (<= 4096 fits 16 bits)
@@ -706,15 +716,15 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                 i64 idx = (i64)tile - 1;
                 bool done = false;
                 u32 spins = 0;
+                const long long spin_t0 = wall_clock64();
                 while (!done) {
                     const i64 mine = idx - (i64)tid;
                     u64 v = SK_FLAG_PRE; // before tile 0: inclusive prefix 0
                     if (mine >= 0) {
                         v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        while ((v >> 62) == 0 && spins < SK_SPIN_MAX) {
+                        while ((v >> 62) == 0 && !ks_spin_expired(spin_t0, spins)) {
                             __builtin_amdgcn_s_sleep(1);
                             v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            spins++;
                         }
                     }
                     if ((v >> 62) == 0) { A.ticket[1] = 1; v = SK_FLAG_PRE; } // spin bound expired: flag the error, do not hang
@@ -1126,15 +1136,15 @@ __global__ __launch_bounds__(SK_THREADS) void k_kmerpos_tiles(kp_args A) {
             i64 idx = (i64)tile - 1;
             bool done = false;
             u32 spins = 0;
+            const long long spin_t0 = wall_clock64();
             while (!done) {
                 const i64 mine = idx - (i64)tid;
                 u64 v = SK_FLAG_PRE;
                 if (mine >= 0) {
                     v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while ((v >> 62) == 0 && spins < SK_SPIN_MAX) {
+                    while ((v >> 62) == 0 && !ks_spin_expired(spin_t0, spins)) {
                         __builtin_amdgcn_s_sleep(1);
                         v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        spins++;
                     }
                 }
                 if ((v >> 62) == 0) { A.ticket[1] = 1; v = SK_FLAG_PRE; }

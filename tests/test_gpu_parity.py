@@ -631,3 +631,41 @@ def test_boundary_copies_staged_pinned_and_plain_agree(ctx):
             assert np.array_equal(back, src)
             dbuf.free()
     del b, pin
+
+
+def test_compacting_tiles_and_bounded_outputs_fall_back_exactly(ctx):
+    """scaled > 1 runs the compacting tile kernel with outputs sized by the expected windows / scaled.  Inputs that defeat an
+    economy — a homopolymer whose one hash falls under the threshold keeps EVERY window; a batch of tiny peptides puts more
+    than 254 sequences into one tile — are repeated without it; the context counts the repeats and the results stay exact."""
+    before = ctx.sketch_stats()
+    # (a) one repeated k-mer per sequence: find a residue whose k-mer is kept at scaled = 2
+    k, scaled, mol = 7, 2, "protein"
+    keep = [aa for aa in b"ACDEFGHIKLMNPQRSTVWY" if oracle.hash_murmur(bytes([aa]) * k) <= oracle.max_hash(scaled)]
+    assert keep
+    seqs = [bytes([keep[0]]) * 6000, bytes([keep[-1]]) * 3000] + [bytes([keep[0]]) * 500] * 40
+    res, offs = ks.pack(seqs)
+    assert_sketch_parity(ctx, res, offs, k, scaled, mol)
+    mid = ctx.sketch_stats()
+    assert mid["compact_fallbacks"] + mid["cap_fallbacks"] > before["compact_fallbacks"] + before["cap_fallbacks"]
+    # (b) > 254 sequences per compacting tile
+    rng = np.random.default_rng(3)
+    lens = rng.integers(8, 20, 20000).astype(np.uint64)
+    o2 = np.zeros(len(lens) + 1, np.uint64); np.cumsum(lens, out=o2[1:])
+    r2 = rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8), int(o2[-1])).astype(np.uint8)
+    assert_sketch_parity(ctx, r2, o2, 5, 5, "protein")
+    assert ctx.sketch_stats()["compact_fallbacks"] > mid["compact_fallbacks"]
+    # (c) outputs forced too small: the repeat with window-count sized arrays gives the same sketches
+    res3, offs3 = synth.proteome(4000, stream=99)
+    want = oracle.sketch_batch(res3, offs3, 16, 5, "dayhoff", n_threads=8)
+    os.environ["KS_DEBUG_OUT_CAP"] = "1000"
+    try:
+        got = ctx.sketch_batch(res3, offs3, 16, 5, "dayhoff").to_host()
+    finally:
+        del os.environ["KS_DEBUG_OUT_CAP"]
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert ctx.sketch_stats()["cap_fallbacks"] > mid["cap_fallbacks"]
+    # and a well-behaved batch needs no repeat at all
+    s0 = ctx.sketch_stats()
+    assert_sketch_parity(ctx, res3, offs3, 16, 5, "dayhoff")
+    assert ctx.sketch_stats() == s0
