@@ -73,12 +73,14 @@ struct sk_args {
     u64 max_hash;
     u32 sfix;     // floor(2^48 / ((max_hash >> 32) + 1)): bucket multiplier = (n_windows * sfix) >> 16
     const u8 *lut; // 256-byte encode table for this moltype
-    u32 R;         // tile stride in residues (see sk_r_cand)
+    u32 R;         // tile stride in residues (see sk_r_cand); 0 = packed tiles (tile_g0 gives each tile's first residue)
+    const u64 *tile_g0; // packed tiles: 16-byte aligned residue offset the tile's LDS window starts at
     u32 span;      // residues a shared tile covers from tile * R: SK_TILE, or more for the compacting variant (scaled > 1)
     u32 c_div, c_rcp; // compacting variant: bucket space is positions / c_div (c_rcp = ceil(2^32 / c_div))
     u64 out_cap;   // capacity of out_hash / out_abund (MODE 0): writes beyond it are dropped and the host repeats larger
     u32 use_ticket; // tile ids from the atomic ticket (1) or from blockIdx.x (0)
     u32 le_cap;    // a sequence whose LOCAL end lies beyond this is not this launch's business
+    u32 max_len_tile; // ... nor is one longer than this (packed tiles: PK_MAX_LEN, so that "long" means the same everywhere)
     const u32 *seq_list; // MODE 0: tile_first[n_tiles + 1] (tile -> first sequence); MODE 1: the medium sequences
     const u32 *n_list;   // MODE 1: device-resident length of seq_list
     u32 n_list_cap;      // ... and the allocated length (the smaller one counts)
@@ -179,7 +181,7 @@ KS_DEV void sk_load_seq(sk_seq &q, const sk_args &A, const sk_bounds &B, u32 s_e
     q.ls = B.at(q.s);
     q.le = B.at(q.s + 1);
     const u32 len = q.le - q.ls; // a clamped end only makes a too-long sequence look (still) too long
-    q.nw = (len >= A.k && q.le <= A.le_cap) ? (len - A.k + 1) : 0;
+    q.nw = (len >= A.k && q.le <= A.le_cap && len <= A.max_len_tile) ? (len - A.k + 1) : 0;
     q.mul = sk_bucket_mul(q.nw, A.sfix);
     q.ok = q.nw > 0;
 }
@@ -197,6 +199,73 @@ KS_DEV u32 sk_place_window(const sk_args &A, u32 p, u64 h, sk_seq &q, const sk_b
         bo = ((srel < 254u ? srel : 254u) << 24) | (b << 12) | o; // b, o < 4096
     }
     return bo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed tiles (plain variant, scaled = 1): instead of cutting the batch at fixed residue strides — where a stride of 3312
+// leaves 19 % of a tile's 4096 positions empty so that few sequences straddle a tile's end — tiles are packed greedily
+// with WHOLE sequences: tile = the longest run of consecutive sequences whose residues fit the LDS window from the
+// (16-byte aligned) start of the first.  ~95 % of the positions carry windows, ~14 % fewer tiles, and no sequence is
+// ever deferred for its position: only those longer than PK_MAX_LEN go to the global-slab path (as the deferred tail of
+// the tile they follow).  The greedy cut is sequential, so it runs per chunk of PK_CHUNK sequences (a tile never spans
+// chunks: one short tile per 1024 sequences): one wave per chunk walks its offsets in LDS with 64-ary searches;
+// k_pack_fill then lays the chunks' tiles out densely.
+// ---------------------------------------------------------------------------------------------
+#define PK_CHUNK 1024
+#define PK_MAX_LEN (SK_MED_MAX - 16) // fits the window wherever its first residue falls inside the aligned 16 bytes
+
+__global__ __launch_bounds__(64) void k_pack_walk(const u64 *offs, u32 n_seqs, u32 *chunk_tiles /* [n_seqs]: tile starts of chunk c from c * PK_CHUNK */,
+                                                  u32 *chunk_cnt) {
+    __shared__ u64 lo_s[PK_CHUNK + 1];
+    const u32 lane = threadIdx.x;
+    const u32 c0 = blockIdx.x * PK_CHUNK;
+    const u32 n = (n_seqs - c0) < PK_CHUNK ? (n_seqs - c0) : PK_CHUNK; // sequences of this chunk
+    for (u32 i = lane; i <= n; i += 64) lo_s[i] = offs[c0 + i];
+    __builtin_amdgcn_wave_barrier();
+    u32 s = 0, nt = 0;
+    while (s < n) { // (uniform: every lane walks the same chain)
+        const u64 limit = (lo_s[s] & ~15ULL) + SK_MED_MAX; // a sequence fits if it ENDS at or before this residue offset
+        // largest e in [s, n] with lo_s[e] <= limit (lo_s[s] always is): 64-ary search
+        u32 lo = s, hi = n + 1;
+        while (hi - lo > 1) {
+            const u32 step = (hi - lo + 63) / 64;
+            const u32 idx = lo + (lane + 1) * step;
+            const bool ok = idx < hi && lo_s[idx] <= limit;
+            const u64 m = __ballot(ok);
+            const u32 good = m == ~0ULL ? 64u : (u32)__builtin_ctzll(~m); // leading run of lanes that still fit
+            const u32 nlo = lo + good * step;
+            const u32 nhi = lo + (good + 1) * step;
+            lo = nlo < hi ? nlo : hi - 1;
+            hi = nhi < hi ? nhi : hi;
+        }
+        u32 e = lo; // sequences [s, e) fit
+        if (e == s) e = s + 1;                           // a long sequence on its own (it is the tile's deferred tail)
+        else if (e < n && lo_s[e + 1] - lo_s[e] > PK_MAX_LEN) e++; // the long sequence that follows rides along as the tail
+        if (lane == 0) chunk_tiles[c0 + nt] = c0 + s;
+        nt++;
+        s = e;
+    }
+    if (lane == 0) chunk_cnt[blockIdx.x] = nt;
+}
+
+// dense plan: tile_first[t] / tile_g0[t] for the tiles of all chunks in order; tile_first[n_tiles] = n_seqs; *n_tiles_out
+__global__ __launch_bounds__(256) void k_pack_fill(const u64 *offs, u32 n_seqs, const u32 *chunk_tiles, const u32 *chunk_cnt, u32 n_chunks,
+                                                   u32 *tile_first, u64 *tile_g0, u32 *n_tiles_out) {
+    __shared__ u32 scan_smem[256 / 64 + 1];
+    u32 part = 0;
+    for (u32 c = threadIdx.x; c < blockIdx.x; c += 256) part += chunk_cnt[c];
+    u32 total;
+    (void)ks_block_excl_scan(part, scan_smem, &total); // total = tiles of the chunks before this one
+    const u32 base = total, mine = chunk_cnt[blockIdx.x];
+    for (u32 i = threadIdx.x; i < mine; i += 256) {
+        const u32 sf = chunk_tiles[blockIdx.x * PK_CHUNK + i];
+        tile_first[base + i] = sf;
+        tile_g0[base + i] = offs[sf] & ~15ULL;
+    }
+    if (blockIdx.x == n_chunks - 1 && threadIdx.x == 0) {
+        tile_first[base + mine] = n_seqs;
+        *n_tiles_out = base + mine;
+    }
 }
 
 // tile_first[t] = first sequence whose start offset is >= t * R (n_tiles + 1 entries): one parallel
@@ -321,7 +390,10 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         *(uint4 *)(res_b + (size_t)tid * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     };
     uint4 rv = make_uint4(0, 0, 0, 0);
-    if (MODE == 0 && tid < NCH) rv = load_chunk((u64)tile * A.R + (u64)tid * 16); // R is a multiple of 16
+    const bool packed = MODE == 0 && !CMP && A.R == 0; // (uniform) packed tiles: the window starts where the plan says
+    u64 g0p = 0;
+    if (packed) g0p = A.tile_g0[tile];
+    if (MODE == 0 && tid < NCH) rv = load_chunk((packed ? g0p : (u64)tile * A.R) + (u64)tid * 16); // R is a multiple of 16
     u32 s_first, s_end;
     if (MODE == 1) { s_first = A.seq_list[tile]; s_end = s_first + 1; }
     else { s_first = A.seq_list[tile]; s_end = A.seq_list[tile + 1]; }
@@ -331,7 +403,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         return;
     }
     // local coordinates: MODE 0 counts from the tile's first byte, MODE 1 from the (aligned) start of its sequence
-    const u64 g0 = MODE == 0 ? (u64)tile * A.R : (A.offs[s_first] & ~15ULL); // A.res is 16-byte aligned (checked on the host)
+    const u64 g0 = MODE == 0 ? (packed ? g0p : (u64)tile * A.R) : (A.offs[s_first] & ~15ULL); // A.res is 16-byte aligned (checked on the host)
     const u32 ns = s_end - s_first;
     sk_bounds B;
     B.loff = loff; B.goff = A.offs; B.g0 = g0; B.s_first = s_first; B.in_lds = ns <= SK_SEQ_CAP;
@@ -683,7 +755,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             // (first bucket of the sequence: its local start, or the compacted base the bucket table holds)
             const u32 d0 = drank(bstart(CMP ? ((const uint2 *)res_w)[s - s_first].x : ls));
             if (B.in_lds) dseq[s - s_first] = (u16)d0;
-            if (le > A.le_cap) {
+            if (le > A.le_cap || le - ls > A.max_len_tile) {
                 const u32 e = atomicAdd(&ext_n, 1u);
                 if (e < 4) { ext_seq[e] = s; ext_cnt[e] = A.counts[s]; ext_d[e] = d0; }
             }
@@ -822,7 +894,8 @@ __global__ __launch_bounds__(256) void k_find_long(const u64 *offs, u32 n_seqs, 
         const u64 len = offs[s + 1] - offs[s];
         // a sequence that does not end inside its shared tile's span is deferred: to a tile of its own if it fits one,
         // else to the global-slab path (with the plain span every sequence longer than SK_MED_MAX is deferred)
-        if (len + 16 > span || sk_deferred(offs[s], len, R, span)) cls = len > SK_MED_MAX ? 1 : 0;
+        if (R == 0) { if (len > PK_MAX_LEN) cls = 1; } // packed tiles: nothing is deferred for its position
+        else if (len + 16 > span || sk_deferred(offs[s], len, R, span)) cls = len > SK_MED_MAX ? 1 : 0;
     }
     // one atomic per wave and class (the lists are short but every thread would hit the same two counters)
 #pragma unroll
@@ -1243,6 +1316,7 @@ int ks_kmerpos_tiles_launch(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32
 struct sk_cands { u32 r[SK_NR]; };
 __global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, u32 k, u32 span, sk_cands cand, u64 *out) {
     u64 w = 0, mx = 0;
+    u32 npk = 0; // sequences longer than PK_MAX_LEN (the long ones of a packed plan)
     u32 nd[SK_NR], nl[SK_NR];
 #pragma unroll
     for (int c = 0; c < SK_NR; c++) { nd[c] = 0; nl[c] = 0; }
@@ -1250,6 +1324,7 @@ __global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, 
         const u64 st = offs[s], len = offs[s + 1] - st;
         w += len >= k ? len - k + 1 : 0;
         mx = len > mx ? len : mx;
+        npk += len > PK_MAX_LEN ? 1u : 0u;
         // (a sequence no longer than span - 15 - R fits wherever it starts: no 64-bit modulo for those; the two widest
         // strides are only ever taken when EVERY sequence is that short, so they are not counted)
 #pragma unroll
@@ -1262,11 +1337,13 @@ __global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, 
     }
     for (int d = 32; d > 0; d >>= 1) {
         w += __shfl_down(w, d, 64);
+        npk += __shfl_down(npk, d, 64);
         u64 o = __shfl_down(mx, d, 64);
         mx = o > mx ? o : mx;
 #pragma unroll
         for (int c = 0; c < SK_NR; c++) { nd[c] += __shfl_down(nd[c], d, 64); nl[c] += __shfl_down(nl[c], d, 64); }
     }
+    if ((threadIdx.x & 63) == 0 && npk) atomicAdd((unsigned long long *)&out[2], (unsigned long long)npk);
     // one set of device atomics per WORKGROUP (they all hit the same few words: per wave they were the whole run time)
     __shared__ u64 red[4][2 + 2 * SK_NR];
     const u32 wave = threadIdx.x >> 6;
@@ -1312,6 +1389,9 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     u64 win_bound = 0;                      // k-mer windows of the batch, or an upper bound (n_res) until the final read
     u32 real_max = 0, tile_R = sk_r_cand_host[0];
     const bool planned = max_seq_len > 0 && !getenv("KS_DEBUG_NO_PLAN");
+    u32 *pk_tiles = nullptr, *pk_cnt = nullptr, *d_ntiles = nullptr;
+    u64 *tile_g0 = nullptr;
+    u64 pk_n_tiles = 0; // packed plan: tiles of the batch (read back with the statistics)
     // compacting variant: bucket space = positions / c_div, span = residues per shared tile (see k_sketch_tiles<0, 1>)
     const bool compact = (variant & 1) && p->scaled >= 2 && !getenv("KS_DEBUG_NO_COMPACT");
     const u32 c_div = compact ? (p->scaled < 64 ? p->scaled : 64u) : 1u;
@@ -1325,6 +1405,9 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             if (v >= SK_TILE && v <= sp) span = v;
         }
     }
+    // packed tiles (whole sequences packed greedily into each tile, see k_pack_walk) for the plain variant
+    const bool packed = !compact && !getenv("KS_DEBUG_NO_PACK");
+    const u32 pk_chunks = (n_seqs + PK_CHUNK - 1) / PK_CHUNK;
     sk_cands cand;
     for (int c = 0; c < SK_NR; c++) cand.r[c] = sk_r_cand_host[c] + (span - SK_TILE);
 #define SK_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
@@ -1348,12 +1431,29 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         ks_timer_begin(ctx, "seq_stats");
         hipLaunchKernelGGL(k_seq_stats, dim3(g), dim3(256), 0, ctx->stream, d_offs, n_seqs, p->ksize, span, cand, d_stats);
         ks_timer_end(ctx);
-        if (!planned) {
+        if (packed) {
+            // The tile count of a packed plan is only known on the device and sizes the launch: it is read back here, with
+            // the statistics (one round trip whether or not the caller gave max_seq_len).
+            SK_CHECK(ks_alloc(ctx, &pk_tiles, (size_t)n_seqs));
+            SK_CHECK(ks_alloc(ctx, &pk_cnt, (size_t)pk_chunks));
+            SK_CHECK(ks_alloc(ctx, &d_ntiles, 1));
+            SK_CHECK(ks_alloc(ctx, &tile_first, (size_t)n_seqs + 1)); // (a tile holds at least one sequence)
+            SK_CHECK(ks_alloc(ctx, &tile_g0, (size_t)n_seqs + 1));
+            ks_timer_begin(ctx, "tile_plan");
+            hipLaunchKernelGGL(k_pack_walk, dim3(pk_chunks), dim3(64), 0, ctx->stream, d_offs, n_seqs, pk_tiles, pk_cnt);
+            hipLaunchKernelGGL(k_pack_fill, dim3(pk_chunks), dim3(256), 0, ctx->stream, d_offs, n_seqs, (const u32 *)pk_tiles, (const u32 *)pk_cnt,
+                               pk_chunks, tile_first, tile_g0, d_ntiles);
+            ks_timer_end(ctx);
+            SK_HIPCHECK(hipGetLastError());
+            SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin + 32, d_ntiles, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (!planned || packed) {
             // no upper bound on the sequence length from the caller: the plan (tile stride, deferred sequences, slab size)
             // comes from the batch itself, at the price of one device -> host round trip before the tiles are launched
             SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, (4 + 2 * SK_NR) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
             SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
             win_bound = ctx->h_pin[0];
+            if (packed) pk_n_tiles = *(u32 *)(ctx->h_pin + 32);
             if (ctx->h_pin[1] > 0xfffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "sequence longer than 2^32 residues"); goto done; }
             real_max = (u32)ctx->h_pin[1];
             // tile stride: fewest (tiles x sub-tiles + 1.75 x medium + 20 x long sequences), see sk_r_cand
@@ -1368,6 +1468,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             if (const char *force = getenv("KS_DEBUG_TILE_R")) // tuning aid: one of sk_r_cand (counted strides only)
                 for (int c = 0; c < SK_NR - 2; c++)
                     if (atoi(force) == (int)sk_r_cand_host[c]) { tile_R = cand.r[c]; n_med = ctx->h_pin[4 + c]; n_long = ctx->h_pin[4 + SK_NR + c]; }
+            if (packed) { tile_R = 0; n_med = 0; n_long = ctx->h_pin[2]; } // nothing is deferred for its position
         } else {
             // max_seq_len given: everything the launches need follows from it, and what is only known on the device (how
             // many sequences are deferred) is read there by kernels with fixed grids.  The widest stride whose tiles hold
@@ -1409,7 +1510,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         }
         A.lut = ctx->d_lut + 256 * p->moltype;
         A.counts = counts;
-        A.span = SK_TILE; A.c_div = 1; A.c_rcp = 0; A.out_cap = out_cap;
+        A.span = SK_TILE; A.c_div = 1; A.c_rcp = 0; A.out_cap = out_cap; A.max_len_tile = 0xffffffffu; A.R = 1;
         SK_CHECK(ks_alloc(ctx, &ticket, 2));
         SK_HIPCHECK(hipMemsetAsync(ticket, 0, 2 * sizeof(u32), ctx->stream));
         A.ticket = ticket;
@@ -1482,15 +1583,18 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         }
 
         // ---- shared tiles: hash + sort/unique + CSR placement in one kernel (decoupled look-back across tiles)
-        const u64 n_tiles = n_res / tile_R + 1;
+        const u64 n_tiles = packed ? pk_n_tiles : n_res / tile_R + 1;
         if (n_tiles > 0x7ffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "batch too large"); goto done; }
-        SK_CHECK(ks_alloc(ctx, &tile_first, (size_t)n_tiles + 1));
-        SK_CHECK(ks_alloc(ctx, &tile_status, (size_t)n_tiles));
+        SK_CHECK(ks_alloc(ctx, &tile_status, (size_t)n_tiles + 1));
         SK_HIPCHECK(hipMemsetAsync(tile_status, 0, (size_t)n_tiles * sizeof(unsigned long long), ctx->stream));
-        ks_timer_begin(ctx, "tile_plan");
-        hipLaunchKernelGGL(k_tile_plan, dim3((u32)((n_tiles + 256) / 256)), dim3(256), 0, ctx->stream, d_offs, n_seqs, (u32)n_tiles, tile_R, tile_first);
-        ks_timer_end(ctx);
-        A.seq_list = tile_first; A.le_cap = span - 16; A.R = tile_R; A.span = span;
+        if (!packed) {
+            SK_CHECK(ks_alloc(ctx, &tile_first, (size_t)n_tiles + 1));
+            ks_timer_begin(ctx, "tile_plan");
+            hipLaunchKernelGGL(k_tile_plan, dim3((u32)((n_tiles + 256) / 256)), dim3(256), 0, ctx->stream, d_offs, n_seqs, (u32)n_tiles, tile_R, tile_first);
+            ks_timer_end(ctx);
+        }
+        A.seq_list = tile_first; A.le_cap = span - 16; A.R = tile_R; A.span = span; A.tile_g0 = tile_g0;
+        if (packed) A.max_len_tile = PK_MAX_LEN;
         if (compact) { A.c_div = c_div; A.c_rcp = (u32)(((1ULL << 32) + c_div - 1) / c_div); }
         A.out_hash = S->d_hashes; A.out_abund = S->d_abunds; A.csr = S->d_offsets;
         A.tile_status = tile_status; A.n_tiles = (u32)n_tiles;
@@ -1575,6 +1679,7 @@ done:
     ks_pool_free(ctx, counts); ks_pool_free(ctx, tile_first); ks_pool_free(ctx, tile_status); ks_pool_free(ctx, ticket); ks_pool_free(ctx, part_snap);
     ks_pool_free(ctx, d_stats); ks_pool_free(ctx, med_ids); ks_pool_free(ctx, long_ids); ks_pool_free(ctx, n_cls);
     ks_pool_free(ctx, slab64); ks_pool_free(ctx, slab32); ks_pool_free(ctx, lg_hash); ks_pool_free(ctx, lg_abund);
+    ks_pool_free(ctx, pk_tiles); ks_pool_free(ctx, pk_cnt); ks_pool_free(ctx, d_ntiles); ks_pool_free(ctx, tile_g0);
     if (st != KS_OK || *redo) {
         (void)hipStreamSynchronize(ctx->stream);
         ks_sketches_free(S);
