@@ -408,6 +408,127 @@ __global__ __launch_bounds__(256) void k_pair_reduce(const u64 *keys, const u32 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sorted match list -> COO rows in ONE pass (packed records): heads, their prefix over the whole list and the per-row
+// sums used to be three passes (k_pair_heads, a device-wide scan, k_pair_reduce) — 0.23 ms of the 1M x 1M step and a quarter
+// of the all-vs-all one, where two records in three open a row.  Here a tile of PF_TILE records keeps its keys in
+// registers: sweep 1 marks the heads (bit per round) and counts them per (round, wave); wave 0 turns the 32 counts into
+// offsets and chains the tile's total through a decoupled look-back (ticket-ordered tiles, 8-byte {flag, value} words);
+// sweep 2 gives every record its row and sums count / abundance per row with the segmented shuffle scan of k_pair_reduce
+// (rows span waves and tiles, so the partial sums are added atomically: ~2 atomics per wave and round).
+// ---------------------------------------------------------------------------------------------
+#define PF_THREADS 256
+#define PF_IPT 8
+#define PF_TILE (PF_THREADS * PF_IPT)
+#define PF_WAVES (PF_THREADS / 64)
+#define PF_FLAG_AGG (1ULL << 62)
+#define PF_FLAG_PRE (2ULL << 62)
+#define PF_VAL_MASK ((1ULL << 62) - 1)
+
+__global__ __launch_bounds__(PF_THREADS) void k_pair_rows_fused(const u64 *keys, u64 n, u32 *qid, u32 *tid, u32 *isect, unsigned long long *nw,
+                                                                int tbits, int abits, u32 rows_cap, unsigned long long *status,
+                                                                u32 *ticket /* [0] tile ids, [1] a look-back gave up */, u32 *n_rows_out) {
+    __shared__ u32 tile_s;
+    __shared__ u32 wcount[PF_IPT][PF_WAVES]; // heads per (round, wave), then exclusive offsets inside the tile
+    __shared__ unsigned long long base_s;
+    const u32 tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6;
+    if (tid_ == 0) tile_s = atomicAdd(&ticket[0], 1u);
+    __syncthreads();
+    const u32 tile = tile_s;
+    const u64 b0 = (u64)tile * PF_TILE;
+    u64 key[PF_IPT];
+    u32 headbits = 0;
+    // sweep 1: record i of round r is b0 + r * PF_THREADS + tid (coalesced); a head opens a row
+#pragma unroll
+    for (int r = 0; r < PF_IPT; r++) {
+        const u64 i = b0 + (u64)r * PF_THREADS + tid_;
+        key[r] = i < n ? keys[i] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < PF_IPT; r++) {
+        const u64 i = b0 + (u64)r * PF_THREADS + tid_;
+        // the previous record: the neighbouring lane's, except for lane 0 (previous wave / round / tile: one extra load)
+        u64 prev = __shfl_up(key[r], 1, 64);
+        if (lane == 0 && i > 0 && i < n) prev = keys[i - 1];
+        const bool head = i < n && (i == 0 || (prev >> abits) != (key[r] >> abits));
+        headbits |= head ? (1u << r) : 0u;
+        const u64 m = __ballot(head);
+        if (lane == 0) wcount[r][wave] = (u32)__popcll(m);
+    }
+    __syncthreads();
+    // wave 0: exclusive offsets of the 32 (round, wave) groups in record order, tile total, look-back
+    if (wave == 0) {
+        const u32 c = lane < PF_IPT * PF_WAVES ? wcount[lane / PF_WAVES][lane % PF_WAVES] : 0u;
+        const u32 incl = ks_wave_incl_scan(c);
+        const u32 total = __shfl(incl, 63, 64);
+        if (lane < PF_IPT * PF_WAVES) wcount[lane / PF_WAVES][lane % PF_WAVES] = incl - c;
+        if (lane == 0)
+            __hip_atomic_store(&status[tile], (tile == 0 ? PF_FLAG_PRE : PF_FLAG_AGG) | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64 excl = 0;
+        if (tile > 0) {
+            i64 idx = (i64)tile - 1;
+            bool done = false;
+            u32 polls = 0;
+            const long long t0 = wall_clock64();
+            while (!done) {
+                const i64 mine = idx - (i64)lane;
+                u64 v = PF_FLAG_PRE; // before tile 0: inclusive prefix 0
+                if (mine >= 0) {
+                    v = __hip_atomic_load(&status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((v >> 62) == 0 && !ks_spin_expired(t0, polls)) {
+                        __builtin_amdgcn_s_sleep(1);
+                        v = __hip_atomic_load(&status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if ((v >> 62) == 0) { ticket[1] = 1; v = PF_FLAG_PRE; } // gave up: the host reports it
+                const u64 is_pre = __ballot((v >> 62) == 2);
+                const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
+                u64 contrib = lane <= first ? (v & PF_VAL_MASK) : 0;
+                for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+                excl += contrib;
+                if (is_pre) done = true; else idx -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&status[tile], PF_FLAG_PRE | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            base_s = excl;
+            if (b0 + PF_TILE >= n) *n_rows_out = (u32)(excl + total); // the last tile knows the row count
+        }
+    }
+    __syncthreads();
+    const u64 base = base_s;
+    // sweep 2: rows and per-row sums
+#pragma unroll
+    for (int r = 0; r < PF_IPT; r++) {
+        const u64 i = b0 + (u64)r * PF_THREADS + tid_;
+        const bool live = i < n;
+        const bool head = (headbits >> r) & 1u;
+        const u64 m = __ballot(head);
+        // heads at or before this record, over the whole list, minus one = its row
+        const u64 row64 = base + wcount[r][wave] + ks_lane_lt_count(m) + (head ? 1u : 0u) - 1u;
+        const u32 row = live ? (u32)row64 : 0xffffffffu;
+        u64 w = live ? (key[r] & ((1ULL << abits) - 1ULL)) : 0;
+        u32 c = live ? 1u : 0u;
+        if (head && row < rows_cap) {
+            const u64 ids = key[r] >> abits;
+            qid[row] = (u32)(ids >> tbits);
+            tid[row] = (u32)(ids & ((1ULL << tbits) - 1ULL));
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { // inclusive segmented scan (segments = equal row, rows ascend)
+            const u64 ow = __shfl_up(w, d, 64);
+            const u32 oc = __shfl_up(c, d, 64), orow = __shfl_up(row, d, 64);
+            if (lane >= (u32)d && orow == row) { w += ow; c += oc; }
+        }
+        const u32 nrow = __shfl_down(row, 1, 64);
+        if (live && (lane == 63 || nrow != row) && row < rows_cap) {
+            atomicAdd(&isect[row], c);
+            atomicAdd(&nw[row], (unsigned long long)w);
+        }
+    }
+}
+
 // One search with the whole query batch in one match list.  *split_pairs != 0 on return (with KS_OK and *out == NULL) means
 // the list would hold that many records — more than one list can (2^32) — and nothing was produced: the caller splits.
 static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out, u64 *split_pairs) {
@@ -424,7 +545,8 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
     const u64 n_q = q->n_hashes, n_t = ix->n_postings;
     u64 *qk0 = nullptr, *qk1 = nullptr, *pk0 = nullptr, *pk1 = nullptr, *row_start = nullptr, *dir_q = nullptr;
     u32 *qv0 = nullptr, *qv1 = nullptr, *pv0 = nullptr, *pv1 = nullptr, *heads = nullptr, *d_nrows = nullptr, *bcur = nullptr;
-    unsigned long long *cursor = nullptr;
+    unsigned long long *cursor = nullptr, *pf_status = nullptr;
+    u32 *pf_ticket = nullptr;
     int st = KS_OK;
     bool split = false;
 #define SE_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
@@ -576,14 +698,22 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             else if (packed) SE_CHECK(ks_radix_sort_keys(ctx, KS_SORT_PAIRS, pk0, pk0, pk1, n_pairs, shifts, ns, &pk));
             else SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_PAIRS, pk0, pv0, pk0, pv0, pk1, pv1, n_pairs, shifts, ns, &pk, &pv));
         }
-        // run-length reduce
-        SE_CHECK(ks_alloc(ctx, &heads, (size_t)n_pairs));
+        // run-length reduce: one fused pass for packed records (k_pair_rows_fused); heads + scan + reduce when the
+        // abundances travel apart (ids + abundance wider than 64 bits)
+        const bool fused = packed && !getenv("KS_DEBUG_UNFUSED_ROWS");
         SE_CHECK(ks_alloc(ctx, &d_nrows, 1));
         const u32 gp = (u32)((n_pairs + 255) / 256);
-        ks_timer_begin(ctx, "pair_heads");
-        hipLaunchKernelGGL(k_pair_heads, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, n_pairs, heads, abits);
-        ks_timer_end(ctx);
-        SE_CHECK(ks_scan_u32_inplace(ctx, heads, n_pairs, d_nrows));
+        const u32 pf_tiles = (u32)((n_pairs + PF_TILE - 1) / PF_TILE);
+        if (fused) {
+            SE_CHECK(ks_alloc(ctx, (u64 **)&pf_status, (size_t)pf_tiles));
+            SE_CHECK(ks_alloc(ctx, &pf_ticket, 2));
+        } else {
+            SE_CHECK(ks_alloc(ctx, &heads, (size_t)n_pairs));
+            ks_timer_begin(ctx, "pair_heads");
+            hipLaunchKernelGGL(k_pair_heads, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, n_pairs, heads, abits);
+            ks_timer_end(ctx);
+            SE_CHECK(ks_scan_u32_inplace(ctx, heads, n_pairs, d_nrows));
+        }
         // The row count is only known on the device here.  Instead of a round trip before the reduce, the row arrays take
         // their size from the previous search of this context (+ 25 %) and the count is read with the final
         // synchronisation; a search that produced more rows than that repeats the (cheap) reduce with exact arrays.
@@ -595,15 +725,26 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             SE_CHECK(ks_alloc(ctx, &H->d_isect, (size_t)rows_cap)); SE_CHECK(ks_alloc(ctx, &H->d_nw, (size_t)rows_cap));
             SE_HIP(hipMemsetAsync(H->d_isect, 0, (size_t)rows_cap * sizeof(u32), ctx->stream));
             SE_HIP(hipMemsetAsync(H->d_nw, 0, (size_t)rows_cap * sizeof(u64), ctx->stream));
-            ks_timer_begin(ctx, "pair_reduce");
-            hipLaunchKernelGGL(k_pair_reduce, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv, (const u32 *)heads,
-                               n_pairs, H->d_qid, H->d_tid, H->d_isect, (unsigned long long *)H->d_nw, tbits, abits, (u32)rows_cap);
-            ks_timer_end(ctx);
+            if (fused) {
+                SE_HIP(hipMemsetAsync(pf_status, 0, (size_t)pf_tiles * sizeof(u64), ctx->stream));
+                SE_HIP(hipMemsetAsync(pf_ticket, 0, 2 * sizeof(u32), ctx->stream));
+                ks_timer_begin(ctx, "pair_rows");
+                hipLaunchKernelGGL(k_pair_rows_fused, dim3(pf_tiles), dim3(PF_THREADS), 0, ctx->stream, (const u64 *)pk, n_pairs, H->d_qid, H->d_tid,
+                                   H->d_isect, (unsigned long long *)H->d_nw, tbits, abits, (u32)rows_cap, pf_status, pf_ticket, d_nrows);
+                ks_timer_end(ctx);
+                SE_HIP(hipMemcpyAsync(ctx->h_pin + 1, pf_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+            } else {
+                ks_timer_begin(ctx, "pair_reduce");
+                hipLaunchKernelGGL(k_pair_reduce, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv, (const u32 *)heads,
+                                   n_pairs, H->d_qid, H->d_tid, H->d_isect, (unsigned long long *)H->d_nw, tbits, abits, (u32)rows_cap);
+                ks_timer_end(ctx);
+            }
             SE_HIP(hipGetLastError());
             SE_HIP(hipMemcpyAsync(ctx->h_pin, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
             SE_CHECK(ks_scan_status_fetch(ctx));
             SE_HIP(hipStreamSynchronize(ctx->stream));
             SE_CHECK(ks_scan_status_check(ctx));
+            if (fused && ((u32 *)(ctx->h_pin + 1))[1] != 0) { st = ks_fail(ctx, KS_ERR_HIP, "search: row look-back gave up waiting for a predecessor tile"); goto done; }
             n_rows = *(u32 *)ctx->h_pin;
             if (n_rows <= rows_cap) break;
             ks_pool_free(ctx, H->d_qid); ks_pool_free(ctx, H->d_tid); ks_pool_free(ctx, H->d_isect); ks_pool_free(ctx, H->d_nw);
@@ -620,7 +761,7 @@ done:
     ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
     ks_pool_free(ctx, pk0); ks_pool_free(ctx, pk1); ks_pool_free(ctx, pv0); ks_pool_free(ctx, pv1);
     ks_pool_free(ctx, heads); ks_pool_free(ctx, d_nrows); ks_pool_free(ctx, row_start); ks_pool_free(ctx, cursor);
-    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, bcur);
+    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, bcur); ks_pool_free(ctx, pf_status); ks_pool_free(ctx, pf_ticket);
     if (st != KS_OK || split) { (void)hipStreamSynchronize(ctx->stream); ks_hits_free(H); return st; }
     *out = H;
     return KS_OK;

@@ -214,12 +214,12 @@ KS_DEV u32 sk_place_window(const sk_args &A, u32 p, u64 h, sk_seq &q, const sk_b
 #define PK_CHUNK 1024
 #define PK_MAX_LEN (SK_MED_MAX - 16) // fits the window wherever its first residue falls inside the aligned 16 bytes
 
-__global__ __launch_bounds__(64) void k_pack_walk(const u64 *offs, u32 n_seqs, u32 *chunk_tiles /* [n_seqs]: tile starts of chunk c from c * PK_CHUNK */,
-                                                  u32 *chunk_cnt) {
+__global__ __launch_bounds__(64) void k_pack_walk(const u64 *offs, u32 n_seqs, u32 chunk /* <= PK_CHUNK sequences per chunk */,
+                                                  u32 *chunk_tiles /* [n_seqs]: tile starts of chunk c from c * chunk */, u32 *chunk_cnt) {
     __shared__ u64 lo_s[PK_CHUNK + 1];
     const u32 lane = threadIdx.x;
-    const u32 c0 = blockIdx.x * PK_CHUNK;
-    const u32 n = (n_seqs - c0) < PK_CHUNK ? (n_seqs - c0) : PK_CHUNK; // sequences of this chunk
+    const u32 c0 = blockIdx.x * chunk;
+    const u32 n = (n_seqs - c0) < chunk ? (n_seqs - c0) : chunk; // sequences of this chunk
     for (u32 i = lane; i <= n; i += 64) lo_s[i] = offs[c0 + i];
     __builtin_amdgcn_wave_barrier();
     u32 s = 0, nt = 0;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64) void k_pack_walk(const u64 *offs, u32 n_seqs, u
 }
 
 // dense plan: tile_first[t] / tile_g0[t] for the tiles of all chunks in order; tile_first[n_tiles] = n_seqs; *n_tiles_out
-__global__ __launch_bounds__(256) void k_pack_fill(const u64 *offs, u32 n_seqs, const u32 *chunk_tiles, const u32 *chunk_cnt, u32 n_chunks,
+__global__ __launch_bounds__(256) void k_pack_fill(const u64 *offs, u32 n_seqs, u32 chunk, const u32 *chunk_tiles, const u32 *chunk_cnt, u32 n_chunks,
                                                    u32 *tile_first, u64 *tile_g0, u32 *n_tiles_out) {
     __shared__ u32 scan_smem[256 / 64 + 1];
     u32 part = 0;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_pack_fill(const u64 *offs, u32 n_seqs, 
     (void)ks_block_excl_scan(part, scan_smem, &total); // total = tiles of the chunks before this one
     const u32 base = total, mine = chunk_cnt[blockIdx.x];
     for (u32 i = threadIdx.x; i < mine; i += 256) {
-        const u32 sf = chunk_tiles[blockIdx.x * PK_CHUNK + i];
+        const u32 sf = chunk_tiles[blockIdx.x * chunk + i];
         tile_first[base + i] = sf;
         tile_g0[base + i] = offs[sf] & ~15ULL;
     }
@@ -370,6 +370,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     if (tid == 0) { ext_n_heavy = 0; ext_n = 0; n_list_s = 0; }
     if (MODE == 0) {
         // tiles are handed out in ticket order, so every predecessor a look-back waits for is already running
+        // (this barrier also orders the LUT staged above before the threads that encode residues through it)
         if (tid == 0) tile_s = ticket_v;
         __syncthreads();
         tile = tile_s;
@@ -1407,7 +1408,10 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     }
     // packed tiles (whole sequences packed greedily into each tile, see k_pack_walk) for the plain variant
     const bool packed = !compact && !getenv("KS_DEBUG_NO_PACK");
-    const u32 pk_chunks = (n_seqs + PK_CHUNK - 1) / PK_CHUNK;
+    // (the walk of a chunk is a serial chain, ~0.5 us per tile: small batches take shorter chunks — more waves, shorter
+    // chains — at the price of one partly filled tile per chunk)
+    const u32 pk_chunk = n_seqs >= 262144 ? PK_CHUNK : (n_seqs >= 32768 ? 256u : 64u);
+    const u32 pk_chunks = (n_seqs + pk_chunk - 1) / pk_chunk;
     sk_cands cand;
     for (int c = 0; c < SK_NR; c++) cand.r[c] = sk_r_cand_host[c] + (span - SK_TILE);
 #define SK_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
@@ -1440,9 +1444,9 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             SK_CHECK(ks_alloc(ctx, &tile_first, (size_t)n_seqs + 1)); // (a tile holds at least one sequence)
             SK_CHECK(ks_alloc(ctx, &tile_g0, (size_t)n_seqs + 1));
             ks_timer_begin(ctx, "tile_plan");
-            hipLaunchKernelGGL(k_pack_walk, dim3(pk_chunks), dim3(64), 0, ctx->stream, d_offs, n_seqs, pk_tiles, pk_cnt);
-            hipLaunchKernelGGL(k_pack_fill, dim3(pk_chunks), dim3(256), 0, ctx->stream, d_offs, n_seqs, (const u32 *)pk_tiles, (const u32 *)pk_cnt,
-                               pk_chunks, tile_first, tile_g0, d_ntiles);
+            hipLaunchKernelGGL(k_pack_walk, dim3(pk_chunks), dim3(64), 0, ctx->stream, d_offs, n_seqs, pk_chunk, pk_tiles, pk_cnt);
+            hipLaunchKernelGGL(k_pack_fill, dim3(pk_chunks), dim3(256), 0, ctx->stream, d_offs, n_seqs, pk_chunk, (const u32 *)pk_tiles,
+                               (const u32 *)pk_cnt, pk_chunks, tile_first, tile_g0, d_ntiles);
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
             SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin + 32, d_ntiles, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));

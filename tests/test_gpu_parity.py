@@ -584,7 +584,7 @@ def test_match_sort_msd_equals_lsd_and_survives_skew(ctx):
     key = want[0].astype(np.uint64) << np.uint64(32) | want[1].astype(np.uint64)
     assert np.all(key[1:] > key[:-1]) and int(want[2].sum()) == base.n_pair_instances
     for env in ({"KS_DEBUG_PAIRS_LSD": "1"}, {"KS_DEBUG_MSD_LDS_CAP": "64"}, {"KS_DEBUG_MSD_LDS_CAP": "700"},
-                {"KS_DEBUG_UNPACKED_PAIRS": "1"}):
+                {"KS_DEBUG_UNPACKED_PAIRS": "1"}, {"KS_DEBUG_UNFUSED_ROWS": "1"}, {"KS_DEBUG_NO_ROWS_HINT": "1"}):
         os.environ.update(env)
         try:
             got = ctx.search(ix, Q).to_host()
