@@ -238,9 +238,9 @@ void ks_hits_free(ks_hits *h);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 
-/* Per-kernel HIP-event timing on ctx's stream.  enable: 0 off; 1 events bracket every launch; 2 only the
- * kernels that move the bulk of the bytes (sketch tiles, query partition, join) — ~0.1 ms of event overhead per
- * batch instead of ~0.9 ms. */
+/* Per-kernel HIP-event timing on ctx's stream.  enable: 0 off; 1 events bracket every launch (~20 us of idle queue
+ * around each: for an untimed diagnostic pass); 2 only the sketch tile kernel — the one a step's roofline is quoted
+ * for — so that a timed region pays for one bracket per batch. */
 typedef struct ks_kernel_time {
     char name[48];
     uint64_t launches;

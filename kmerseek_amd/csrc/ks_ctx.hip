@@ -260,14 +260,10 @@ static void timer_resolve(ks_ctx *ctx) {
     ctx->t_pending.clear();
 }
 
-// the kernels that move the bulk of the bytes: the only ones bracketed in mode 2
-static bool timer_is_major(const char *name) {
-    static const char *const major[] = {"sketch_tiles", "bucket_scatter", "radix_scatter.qpart", "radix_hist.qpart", "join_buckets",
-                                        "radix_scatter.index", "sketch_long", "sketch_medium", "msd_scatter", "msd_local"};
-    for (const char *m : major)
-        if (!strcmp(name, m)) return true;
-    return false;
-}
+// mode 2 brackets only the kernel the roofline is quoted for: every bracketed launch costs two event records, and the
+// kernel trace shows 10-28 us of idle queue around each of them (profiles/README.md) — a per-step tax a timed region
+// should not pay for kernels whose durations the untimed full pass (mode 1) gives as well
+static bool timer_is_major(const char *name) { return !strcmp(name, "sketch_tiles"); }
 
 void ks_timer_begin(ks_ctx *ctx, const char *name) {
     ctx->t_open = false;

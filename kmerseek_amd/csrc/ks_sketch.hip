@@ -88,6 +88,7 @@ struct sk_args {
     u64 *out_hash;  // MODE 0: final hashes [n_windows]; MODE 1: lg_hash [n_res] (run of sequence s starts at offs[s])
     u32 *out_abund;
     u64 *csr;       // [n_seqs + 1] final CSR offsets (MODE 0)
+    u64 *total_out; // MODE 0: the batch's kept-hash total once more, next to the other words the host reads back
     u32 *counts;    // [n_seqs] unique hashes of medium / long sequences (written by MODE 1 / k_sketch_long, read by MODE 0)
     // decoupled look-back across tiles (MODE 0)
     unsigned long long *tile_status; // [n_tiles] (flag << 62) | value; flag 1 = tile aggregate, 2 = inclusive prefix
@@ -147,6 +148,7 @@ KS_DEV bool sk_deferred(u64 start, u64 len, u32 R, u32 span) { return start % R 
 // floor(x / d) for x < 2^32 / d with rcp = ceil(2^32 / d) (d = 1: rcp does not fit, handled apart)
 KS_DEV u32 sk_div(u32 x, u32 d, u32 rcp) { return d == 1 ? x : __umulhi(x, rcp); }
 
+#define SK_CTL_WORDS 32 // control block of a sketch call (see sketch_attempt)
 #define SK_SEQ_CAP 254 // sequence boundaries of a tile staged in LDS (tiles with more fall back to global reads)
 // per-element code: sequence (relative to the tile's first, 8 bits) | bucket (12 bits) | arrival slot (12 bits)
 #define SK_BO_B(x) (((x) >> 12) & 0xfffu)
@@ -822,7 +824,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             for (u32 e = 0; e < ne; e++) pos += ext_seq[e] < s ? ext_cnt[e] : 0;
             A.csr[s] = pos;
         }
-        if (s_end == A.n_seqs && tid == 0) A.csr[A.n_seqs] = base + agg;
+        if (s_end == A.n_seqs && tid == 0) { A.csr[A.n_seqs] = base + agg; *A.total_out = base + agg; }
         if (!B.in_lds) { // rare: more sequences than the LDS table holds, so the starts were needed until here
             __syncthreads();
             stage_reps();
@@ -1428,8 +1430,12 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     }
     {
         // windows, longest sequence, medium / long counts per candidate stride
-        SK_CHECK(ks_alloc(ctx, &d_stats, 4 + 2 * SK_NR));
-        SK_HIPCHECK(hipMemsetAsync(d_stats, 0, (4 + 2 * SK_NR) * sizeof(u64), ctx->stream));
+        // every small word the host zeroes before / reads after the launches lives in ONE control block — one memset, one
+        // device -> host copy per read-back instead of one per word (each is a dispatch of its own on this runtime):
+        // [0, 20) statistics, [20] ticket + status bits, [21] medium / long counts, [22] tiles of a packed plan, [23] kept hashes
+        SK_CHECK(ks_alloc(ctx, &d_stats, SK_CTL_WORDS));
+        SK_HIPCHECK(hipMemsetAsync(d_stats, 0, SK_CTL_WORDS * sizeof(u64), ctx->stream));
+        ticket = (u32 *)(d_stats + 20); n_cls = (u32 *)(d_stats + 21); d_ntiles = (u32 *)(d_stats + 22);
         u32 g = (n_seqs + 1023) / 1024;
         if (g > 512) g = 512;
         ks_timer_begin(ctx, "seq_stats");
@@ -1440,7 +1446,6 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             // the statistics (one round trip whether or not the caller gave max_seq_len).
             SK_CHECK(ks_alloc(ctx, &pk_tiles, (size_t)n_seqs));
             SK_CHECK(ks_alloc(ctx, &pk_cnt, (size_t)pk_chunks));
-            SK_CHECK(ks_alloc(ctx, &d_ntiles, 1));
             SK_CHECK(ks_alloc(ctx, &tile_first, (size_t)n_seqs + 1)); // (a tile holds at least one sequence)
             SK_CHECK(ks_alloc(ctx, &tile_g0, (size_t)n_seqs + 1));
             ks_timer_begin(ctx, "tile_plan");
@@ -1449,15 +1454,14 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                                (const u32 *)pk_cnt, pk_chunks, tile_first, tile_g0, d_ntiles);
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
-            SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin + 32, d_ntiles, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
         }
         if (!planned || packed) {
             // no upper bound on the sequence length from the caller: the plan (tile stride, deferred sequences, slab size)
             // comes from the batch itself, at the price of one device -> host round trip before the tiles are launched
-            SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, (4 + 2 * SK_NR) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+            SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, SK_CTL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
             SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
             win_bound = ctx->h_pin[0];
-            if (packed) pk_n_tiles = *(u32 *)(ctx->h_pin + 32);
+            if (packed) pk_n_tiles = *(u32 *)(ctx->h_pin + 22);
             if (ctx->h_pin[1] > 0xfffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "sequence longer than 2^32 residues"); goto done; }
             real_max = (u32)ctx->h_pin[1];
             // tile stride: fewest (tiles x sub-tiles + 1.75 x medium + 20 x long sequences), see sk_r_cand
@@ -1515,9 +1519,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         A.lut = ctx->d_lut + 256 * p->moltype;
         A.counts = counts;
         A.span = SK_TILE; A.c_div = 1; A.c_rcp = 0; A.out_cap = out_cap; A.max_len_tile = 0xffffffffu; A.R = 1;
-        SK_CHECK(ks_alloc(ctx, &ticket, 2));
-        SK_HIPCHECK(hipMemsetAsync(ticket, 0, 2 * sizeof(u32), ctx->stream));
-        A.ticket = ticket;
+        A.ticket = ticket; A.total_out = d_stats + 23;
         if (part_pbits > 0 && S->n_windows > 0 && S->n_windows < 0xffff0000ULL) {
             // first partition digit: the low 8 bits of the join's hash prefix (the whole prefix if it is <= 8 bits)
             const int dbits = part_pbits < 8 ? part_pbits : 8;
@@ -1546,8 +1548,6 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             SK_CHECK(ks_alloc(ctx, &lg_abund, (size_t)n_res + 1));
             SK_CHECK(ks_alloc(ctx, &med_ids, (size_t)n_med + 1));
             SK_CHECK(ks_alloc(ctx, &long_ids, (size_t)n_long + 1));
-            SK_CHECK(ks_alloc(ctx, &n_cls, 2));
-            SK_HIPCHECK(hipMemsetAsync(n_cls, 0, 2 * sizeof(u32), ctx->stream));
             ks_timer_begin(ctx, "find_long");
             hipLaunchKernelGGL(k_find_long, dim3((n_seqs + 255) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, tile_R, span, med_ids, long_ids, n_cls,
                                (u32)n_med, (u32)n_long);
@@ -1603,7 +1603,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         A.out_hash = S->d_hashes; A.out_abund = S->d_abunds; A.csr = S->d_offsets;
         A.tile_status = tile_status; A.n_tiles = (u32)n_tiles;
         // posting cursors as the medium tiles left them (a repeated launch starts from here)
-        if (A.part_cursor) {
+        if (A.part_cursor && n_med > 0) { // (without medium tiles the cursors are still zero: a repeat just clears them)
             SK_CHECK(ks_alloc(ctx, &part_snap, 2048));
             SK_HIPCHECK(hipMemcpyAsync(part_snap, A.part_cursor, 2048 * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
         }
@@ -1615,13 +1615,14 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                 SK_HIPCHECK(hipMemsetAsync(tile_status, 0, (size_t)n_tiles * sizeof(unsigned long long), ctx->stream));
                 // (keeps the status bits the medium tiles set before the loop — "postings not emitted" — and drops only
                 // the look-back flag of the first attempt)
-                const u32 keep_bits = ((u32 *)(ctx->h_pin + 1))[1] & 2u;
+                const u32 keep_bits = ((u32 *)(ctx->h_pin + 20))[1] & 2u;
                 SK_HIPCHECK(hipMemsetAsync(ticket, 0, 2 * sizeof(u32), ctx->stream));
                 if (keep_bits) {
-                    ((u32 *)(ctx->h_pin + 2))[0] = keep_bits;
-                    SK_HIPCHECK(hipMemcpyAsync(ticket + 1, ctx->h_pin + 2, sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+                    ((u32 *)(ctx->h_pin + 30))[0] = keep_bits;
+                    SK_HIPCHECK(hipMemcpyAsync(ticket + 1, ctx->h_pin + 30, sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
                 }
                 if (part_snap) SK_HIPCHECK(hipMemcpyAsync(A.part_cursor, part_snap, 2048 * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+                else if (A.part_cursor) SK_HIPCHECK(hipMemsetAsync(A.part_cursor, 0, 2048 * sizeof(u32), ctx->stream));
             }
             ks_timer_begin(ctx, "sketch_tiles");
             if (compact) hipLaunchKernelGGL((k_sketch_tiles<0, 1>), dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
@@ -1649,25 +1650,23 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             }
             SK_HIPCHECK(hipGetLastError());
             // total + look-back error flag to the host
-            SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, S->d_offsets + n_seqs, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-            SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin + 1, ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-            if (planned) SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin + 4, d_stats, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+            SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, SK_CTL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
             SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
-            u32 &status_w = ((u32 *)(ctx->h_pin + 1))[1];
+            u32 &status_w = ((u32 *)(ctx->h_pin + 20))[1];
             if (attempt == 0 && !A.use_ticket && getenv("KS_DEBUG_FORCE_TICKET_RETRY")) status_w |= 1u; // exercises the repeat
             if (!(status_w & 1u) || A.use_ticket) break;
         }
-        S->n_hashes = ctx->h_pin[0];
+        S->n_hashes = ctx->h_pin[23];
         if (planned) {
-            S->n_windows = ctx->h_pin[4];
-            if (ctx->h_pin[5] > (u64)max_seq_len) { // the plan was made for shorter sequences: nothing of this launch can be trusted
+            S->n_windows = ctx->h_pin[0];
+            if (ctx->h_pin[1] > (u64)max_seq_len) { // the plan was made for shorter sequences: nothing of this launch can be trusted
                 st = ks_fail(ctx, KS_ERR_INVALID_ARG, "max_seq_len = %u, but the batch holds a sequence of %llu residues", max_seq_len,
-                             (unsigned long long)ctx->h_pin[5]);
+                             (unsigned long long)ctx->h_pin[1]);
                 goto done;
             }
         }
         {
-            const u32 status = ((u32 *)(ctx->h_pin + 1))[1];
+            const u32 status = ((u32 *)(ctx->h_pin + 20))[1];
             if (status & 1u) { st = ks_fail(ctx, KS_ERR_HIP, "sketch: tile look-back timed out"); goto done; }
             if (status & 4u) { *redo = 1; goto done; }          // a compacting tile overflowed: the plain variant always fits
             if (S->n_hashes > out_cap) { *redo = 2; goto done; } // more kept hashes than the bounded outputs hold
@@ -1680,10 +1679,10 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     }
 
 done:
-    ks_pool_free(ctx, counts); ks_pool_free(ctx, tile_first); ks_pool_free(ctx, tile_status); ks_pool_free(ctx, ticket); ks_pool_free(ctx, part_snap);
-    ks_pool_free(ctx, d_stats); ks_pool_free(ctx, med_ids); ks_pool_free(ctx, long_ids); ks_pool_free(ctx, n_cls);
+    ks_pool_free(ctx, counts); ks_pool_free(ctx, tile_first); ks_pool_free(ctx, tile_status); ks_pool_free(ctx, part_snap);
+    ks_pool_free(ctx, d_stats); ks_pool_free(ctx, med_ids); ks_pool_free(ctx, long_ids);
     ks_pool_free(ctx, slab64); ks_pool_free(ctx, slab32); ks_pool_free(ctx, lg_hash); ks_pool_free(ctx, lg_abund);
-    ks_pool_free(ctx, pk_tiles); ks_pool_free(ctx, pk_cnt); ks_pool_free(ctx, d_ntiles); ks_pool_free(ctx, tile_g0);
+    ks_pool_free(ctx, pk_tiles); ks_pool_free(ctx, pk_cnt); ks_pool_free(ctx, tile_g0);
     if (st != KS_OK || *redo) {
         (void)hipStreamSynchronize(ctx->stream);
         ks_sketches_free(S);
