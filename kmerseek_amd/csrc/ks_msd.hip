@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_msd_scan256(u32 *hist, u32 n) {
     const u32 v = hist[threadIdx.x];
     const u32 ex = ks_block_excl_scan(v, smem, &total);
     hist[threadIdx.x] = ex;
-    if (threadIdx.x == 0) hist[256] = n; // (bucket directory of a one-level partition: 257 entries)
+    (void)n;
 }
 
 // One partition pass: record -> bin cursor (exact sizes).  Ranks inside (tile, bin) are LDS atomic returns, one global
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_msd_local(u64 *keys, const u32 *
     const u32 wave_cap = lds_cap < ML_WCAP ? lds_cap : ML_WCAP;
     const u32 bw = blockIdx.x * ML_WAVES + wave;
     if (bw < n_buckets) {
-        const u64 s = off[bw], nb64 = (u64)off[bw + 1] - s;
+        const u64 s = bw ? off[bw - 1] : 0, nb64 = (u64)off[bw] - s; // off[b] = END of bucket b (the scatter's cursors, spent)
         if (nb64 > 1 && nb64 <= wave_cap) ml_sort_wave(keys, s, (u32)nb64, lo_bit, rem_bits, wcnt[wave], stage + wave * ML_WCAP, lane);
         else if (nb64 > wave_cap && lane == 0) big[1 + atomicAdd(&big[0], 1u)] = bw; // for k_msd_local_big
     }
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_msd_local_big(u64 *keys, u64 *sc
     const u32 n_big = big[0];
     for (u32 w = blockIdx.x; w < n_big; w += gridDim.x) {
         const u32 bb = big[1 + w];
-        const u64 s = off[bb], e = off[bb + 1];
+        const u64 s = bb ? off[bb - 1] : 0, e = off[bb];
         const u64 nb64 = e - s;
         __syncthreads(); // the previous large bucket is done with LDS
         u64 key[ML_IPT];
@@ -396,27 +396,24 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
         const u32 v = (u32)atoi(f);
         if (v >= 2 && v < ML_CAP) lds_cap = v;
     }
-    u32 *off1 = nullptr, *off2 = nullptr, *cur = nullptr, *big = nullptr;
-    int st = ks_alloc(ctx, &off1, 256 + 1);
+    // off1 | big list share one block so that one memset clears the level-1 histogram and the list's counter.  The exclusive
+    // offsets double as the scatter's cursors: once spent, cursor[b] is the END of bucket b, which is all the local sort needs
+    // (no copy of the offsets is kept).
+    u32 *blk = nullptr, *off2 = nullptr;
+    int st = ks_alloc(ctx, &blk, 256 + 1 + 65536 + 1);
     if (st == KS_OK) st = ks_alloc(ctx, &off2, 65536 + 1);
-    if (st == KS_OK) st = ks_alloc(ctx, &cur, 65536);
-    if (st == KS_OK) st = ks_alloc(ctx, &big, 65536 + 1);
-    if (st == KS_OK) (void)hipMemsetAsync(big, 0, sizeof(u32), ctx->stream);
+    u32 *off1 = blk, *big = blk ? blk + 256 : nullptr;
     u64 *sorted_in = ka; // where the partitioned list ends up
     if (st == KS_OK) {
-        (void)hipMemsetAsync(off1, 0, 257 * sizeof(u32), ctx->stream);
+        (void)hipMemsetAsync(blk, 0, 257 * sizeof(u32), ctx->stream);
         ks_timer_begin(ctx, "msd_hist");
         hipLaunchKernelGGL((k_msd_hist<256>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, n, shift1, off1, 255u, 0);
         ks_timer_end(ctx);
         ks_timer_begin(ctx, "msd_scan");
         hipLaunchKernelGGL(k_msd_scan256, dim3(1), dim3(256), 0, ctx->stream, off1, (u32)n);
         ks_timer_end(ctx);
-        if (hipMemcpyAsync(cur, off1, 256 * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
-            st = ks_fail(ctx, KS_ERR_HIP, "msd sort: cursor copy failed");
-    }
-    if (st == KS_OK) {
         ks_timer_begin(ctx, "msd_scatter");
-        hipLaunchKernelGGL((k_msd_scatter<256>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, kb, n, shift1, cur, 255u, 0);
+        hipLaunchKernelGGL((k_msd_scatter<256>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, kb, n, shift1, off1, 255u, 0);
         ks_timer_end(ctx);
         sorted_in = kb;
     }
@@ -426,12 +423,10 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
         ks_timer_begin(ctx, "msd_hist");
         hipLaunchKernelGGL((k_msd_hist<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, n, shift2, off2, mask2, bits2);
         ks_timer_end(ctx);
-        st = ks_scan_u32_inplace(ctx, off2, n_buckets, off2 + n_buckets);
-        if (st == KS_OK && hipMemcpyAsync(cur, off2, (size_t)n_buckets * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
-            st = ks_fail(ctx, KS_ERR_HIP, "msd sort: cursor copy failed");
+        st = ks_scan_u32_inplace(ctx, off2, n_buckets, nullptr);
         if (st == KS_OK) {
             ks_timer_begin(ctx, "msd_scatter");
-            hipLaunchKernelGGL((k_msd_scatter<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, ka, n, shift2, cur, mask2, bits2);
+            hipLaunchKernelGGL((k_msd_scatter<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, ka, n, shift2, off2, mask2, bits2);
             ks_timer_end(ctx);
             sorted_in = ka;
             off = off2;
@@ -453,6 +448,6 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
         if (st == KS_OK && hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "msd sort launch failed");
         if (st == KS_OK) *done = 1;
     }
-    ks_pool_free(ctx, off1); ks_pool_free(ctx, off2); ks_pool_free(ctx, cur); ks_pool_free(ctx, big);
+    ks_pool_free(ctx, blk); ks_pool_free(ctx, off2);
     return st;
 }

@@ -638,7 +638,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             for (int attempt = 0; attempt < 2; attempt++) {
                 SE_CHECK(ks_alloc(ctx, &pk0, (size_t)cap));
                 if (!packed) SE_CHECK(ks_alloc(ctx, &pv0, (size_t)cap));
-                SE_HIP(hipMemsetAsync(cursor, 0, sizeof(u64), ctx->stream));
+                if (attempt > 0) SE_HIP(hipMemsetAsync(cursor, 0, sizeof(u64), ctx->stream)); // (attempt 0: cleared with the flag word above)
                 ks_timer_begin(ctx, "join_buckets");
                 hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
                                    (const u32 *)qv, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds,
@@ -704,9 +704,9 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         SE_CHECK(ks_alloc(ctx, &d_nrows, 1));
         const u32 gp = (u32)((n_pairs + 255) / 256);
         const u32 pf_tiles = (u32)((n_pairs + PF_TILE - 1) / PF_TILE);
-        if (fused) {
-            SE_CHECK(ks_alloc(ctx, (u64 **)&pf_status, (size_t)pf_tiles));
-            SE_CHECK(ks_alloc(ctx, &pf_ticket, 2));
+        if (fused) { // status words and the ticket pair in one block: one memset
+            SE_CHECK(ks_alloc(ctx, (u64 **)&pf_status, (size_t)pf_tiles + 1));
+            pf_ticket = (u32 *)(pf_status + pf_tiles);
         } else {
             SE_CHECK(ks_alloc(ctx, &heads, (size_t)n_pairs));
             ks_timer_begin(ctx, "pair_heads");
@@ -726,8 +726,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             SE_HIP(hipMemsetAsync(H->d_isect, 0, (size_t)rows_cap * sizeof(u32), ctx->stream));
             SE_HIP(hipMemsetAsync(H->d_nw, 0, (size_t)rows_cap * sizeof(u64), ctx->stream));
             if (fused) {
-                SE_HIP(hipMemsetAsync(pf_status, 0, (size_t)pf_tiles * sizeof(u64), ctx->stream));
-                SE_HIP(hipMemsetAsync(pf_ticket, 0, 2 * sizeof(u32), ctx->stream));
+                SE_HIP(hipMemsetAsync(pf_status, 0, ((size_t)pf_tiles + 1) * sizeof(u64), ctx->stream));
                 ks_timer_begin(ctx, "pair_rows");
                 hipLaunchKernelGGL(k_pair_rows_fused, dim3(pf_tiles), dim3(PF_THREADS), 0, ctx->stream, (const u64 *)pk, n_pairs, H->d_qid, H->d_tid,
                                    H->d_isect, (unsigned long long *)H->d_nw, tbits, abits, (u32)rows_cap, pf_status, pf_ticket, d_nrows);
@@ -761,7 +760,7 @@ done:
     ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
     ks_pool_free(ctx, pk0); ks_pool_free(ctx, pk1); ks_pool_free(ctx, pv0); ks_pool_free(ctx, pv1);
     ks_pool_free(ctx, heads); ks_pool_free(ctx, d_nrows); ks_pool_free(ctx, row_start); ks_pool_free(ctx, cursor);
-    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, bcur); ks_pool_free(ctx, pf_status); ks_pool_free(ctx, pf_ticket);
+    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, bcur); ks_pool_free(ctx, pf_status);
     if (st != KS_OK || split) { (void)hipStreamSynchronize(ctx->stream); ks_hits_free(H); return st; }
     *out = H;
     return KS_OK;
