@@ -241,11 +241,14 @@ def run_queries_sharded(args, env, ks, synth, ksd):
         ctx.sketch_batch(*ks.pack([b"ACDEFGHIKLMNPQRSTVWY" * 40] * 20000), k, scaled, mol).to_host()  # staging buffers exist
         qh_res = q_res[:n_q_res].cpu().numpy()
         qh_off = q_off.cpu().numpy().view(np.uint64)
-        c0 = time.perf_counter()
-        Q = ctx.sketch_batch(qh_res, qh_off, k, scaled, mol)
-        H = ctx.search(index, Q)
-        rows = H.to_host()
-        c1 = time.perf_counter()
+        for rep in range(2):  # the first pass grows the context's pool for this (posting-free) path: the second one is timed
+            if rep:
+                H.free(); Q.free()
+            c0 = time.perf_counter()
+            Q = ctx.sketch_batch(qh_res, qh_off, k, scaled, mol)
+            H = ctx.search(index, Q)
+            rows = H.to_host()
+            c1 = time.perf_counter()
         csr = Q.to_host()                      # pageable numpy arrays: staged through pinned buffers by host threads
         c2p = c2 = time.perf_counter()
         # pinned arrays (ks_host_alloc), allocated beforehand as a caller that streams batches would: one DMA each
