@@ -495,7 +495,8 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
         H = ctx.search(index, Q)
         # per-shard hit lists all-gathered on the device; left in rank-major order (each shard's block is (qid, tid)-ordered),
         # as configs[4] states it — a global (qid, tid) order is one more stable device sort (order="qid") a consumer may ask for
-        rows = ksd.all_gather_hits_device(H, tid_base=s0, device=env.cdev, sharded="index", order="shard")
+        # The rows travel as 64-bit transport words (8 instead of 20 bytes per row over xGMI; rows with wide values on an escape list).
+        rows = ksd.all_gather_hits_device(H, tid_base=s0, device=env.cdev, sharded="index", order="shard", id_counts=(n_prot, n_prot))
         out = (Q.n_hashes, H.count, H.n_pair_instances, int(rows[0].numel()))
         H.free()
         Q.free()
@@ -524,12 +525,13 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
                                f"(BASELINE configs[4]: index sharded by target id, per-shard hit lists all-gathered)",
                    "proteins": n_prot, "ksize": k, "scaled": scaled, "moltype": mol,
                    "parallelism": f"index sharded x{world} by target id, queries replicated, hits all-gathered "
-                                  f"(count exchange + one padded all_gather_into_tensor on device buffers)",
+                                  f"(count exchange + one padded all_gather_into_tensor on device buffers, rows as 64-bit "
+                                  f"transport words)",
                    "n_ranks": world, "collective_backend": env.backend},
         "query_proteins_per_s": n_prot * args.steps / elapsed, "query_windows": q_windows, "query_hashes": stats[0],
         "hits_gathered": n_gathered, "hits_sum_over_shards": local_hits_sum, "gathered_equals_sum_of_shards": n_gathered == local_hits_sum,
         "gathered_pairs_all_distinct": ordered, "self_hits": diag, "matched_posting_pairs_rank0": stats[2],
-        "hit_bytes_gathered_per_step": 20 * n_gathered, "index_build_s": index_build_s, "datagen_s": gen_s,
+        "hit_bytes_gathered_per_step": (8 if world > 1 else 20) * n_gathered, "index_build_s": index_build_s, "datagen_s": gen_s,
     }
 
 

@@ -234,6 +234,15 @@ const uint64_t *ks_hits_device_n_weighted(const ks_hits *h);
  * destination may be NULL. */
 int ks_hits_copy_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qid_base, uint32_t tid_base, uint32_t *d_qid,
                            uint32_t *d_tid, uint32_t *d_intersect, uint64_t *d_n_weighted);
+/* Transport form of the rows for a multi-GPU exchange: one 64-bit word per row,
+ *     qid << (tbits + 2v) | tid << 2v | intersect << v | n_weighted,   v = (64 - qbits - tbits) / 2,
+ * ids in global numbering (qid_base / tid_base added; qbits / tbits = bits of the GLOBAL id ranges, qbits + tbits <= 48).
+ * A row whose intersect or n_weighted needs more than v bits carries all-ones in both value fields and is appended to the
+ * escape list (row index, intersect, n_weighted; *d_n_esc counts them, also past esc_cap — the caller sizes a repeat).
+ * 8 bytes per row instead of 20 over xGMI.  Asynchronous on ctx's stream; *d_n_esc must be zero on entry. */
+int ks_hits_pack64_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qid_base, uint32_t tid_base, int qbits, int tbits,
+                             uint64_t *d_packed, uint32_t *d_esc_row, uint32_t *d_esc_intersect, uint64_t *d_esc_n_weighted,
+                             uint32_t *d_n_esc, uint32_t esc_cap);
 void ks_hits_free(ks_hits *h);
 
 /* ---- measurement --------------------------------------------------------------------------- */

@@ -272,6 +272,42 @@ extern "C" int ks_hits_copy_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qi
     return KS_OK;
 }
 
+// ---- packed transport records (multi-GPU hit exchange) ---------------------------------------------------------------
+// A COO row is 20 bytes (qid u32, tid u32, intersect u32, n_weighted u64); an all-vs-all of 200k proteins gathers 31 M of
+// them, and over xGMI the exchange — not the kernels — is the step.  For transport a row travels as ONE 64-bit word
+//     qid << (tbits + 2v) | tid << 2v | intersect << v | n_weighted,      v = (64 - qbits - tbits) / 2 value bits,
+// ids in global numbering.  A row whose intersect or n_weighted does not fit v bits carries all-ones in both value fields and
+// its true values go to a short escape list (row index, intersect, n_weighted), gathered beside the words.
+__global__ __launch_bounds__(256) void k_hits_pack64(const u32 *qid, const u32 *tid, const u32 *isect, const u64 *nw, u64 n, u32 qid_base,
+                                                     u32 tid_base, int tbits, int vbits, u64 *packed, u32 *esc_row, u32 *esc_isect,
+                                                     u64 *esc_nw, u32 *n_esc, u32 esc_cap) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 vmax = (1ULL << vbits) - 1ULL;
+    u64 a = isect[i], b = nw[i];
+    if (a >= vmax || b >= vmax) { // (all-ones itself is the escape marker, so a value equal to it escapes too)
+        const u32 e = atomicAdd(n_esc, 1u);
+        if (e < esc_cap) { esc_row[e] = (u32)i; esc_isect[e] = (u32)a; esc_nw[e] = b; }
+        a = vmax; b = vmax;
+    }
+    packed[i] = ((((u64)(qid[i] + qid_base) << tbits) | (u64)(tid[i] + tid_base)) << (2 * vbits)) | (a << vbits) | b;
+}
+
+extern "C" int ks_hits_pack64_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qid_base, uint32_t tid_base, int qbits, int tbits,
+                                        uint64_t *d_packed, uint32_t *d_esc_row, uint32_t *d_esc_intersect, uint64_t *d_esc_n_weighted,
+                                        uint32_t *d_n_esc, uint32_t esc_cap) {
+    if (!ctx || !h) return KS_ERR_INVALID_ARG;
+    if (qbits < 1 || tbits < 1 || qbits + tbits > 48) return ks_fail(ctx, KS_ERR_INVALID_ARG, "pack64: %d + %d id bits leave fewer than 8 value bits", qbits, tbits);
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    const u64 n = h->n_hits;
+    if (n == 0) return KS_OK;
+    if (!d_packed || !d_n_esc || (esc_cap && (!d_esc_row || !d_esc_intersect || !d_esc_n_weighted))) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    KS_LAUNCH(ctx, "hits_pack", k_hits_pack64, (u32)((n + 255) / 256), 256, (const u32 *)h->d_qid, (const u32 *)h->d_tid, (const u32 *)h->d_isect,
+              (const u64 *)h->d_nw, n, qid_base, tid_base, tbits, (64 - qbits - tbits) / 2, d_packed, d_esc_row, d_esc_intersect, d_esc_n_weighted,
+              d_n_esc, esc_cap);
+    return KS_OK;
+}
+
 extern "C" void ks_hits_free(ks_hits *h) {
     if (!h) return;
     ks_pool_free(h->ctx, h->d_qid);

@@ -80,19 +80,26 @@ def broadcast_batch(residues: Optional[np.ndarray], offsets: Optional[np.ndarray
     return t_res, t_off
 
 
+def _bits_for(n: int) -> int:
+    return max(1, int(n - 1).bit_length()) if n > 1 else 1
+
+
 def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=None, sharded: str = "queries",
-                           order: str = "qid"):
+                           order: str = "qid", id_counts: Optional[Tuple[int, int]] = None):
     """Concatenate every rank's COO hit list on the device: counts are exchanged first, then ONE padded
     ``all_gather_into_tensor`` moves the rows (RCCL over xGMI with backend "nccl"; gloo on CPU tensors in the tests).
 
-    hits    : a device-resident ``engine.Hits`` — its columns go D2D straight into the send block
-              (``ks_hits_copy_to_device``, ids shifted to global numbering by the copy kernel; no host round trip) —
-              or a numpy 4-tuple of host columns (CPU tensors / gloo).
-    sharded : "queries" — ranks own ascending qid ranges, so the concatenation in rank order already IS (qid, tid) order;
-              "index"   — ranks own ascending tid ranges: the concatenation is ordered by (shard, qid, tid).
-    order   : "qid" (default) — for an index-sharded gather one stable device sort on qid restores global (qid, tid) order;
-              "shard" — leave the rank-major concatenation as it is (every block (qid, tid)-ordered; what BASELINE configs[4]
-              asks for: "all-gather of per-shard hit lists").
+    hits      : a device-resident ``engine.Hits`` — its rows go D2D straight into the send block (no host round trip) —
+                or a numpy 4-tuple of host columns (CPU tensors / gloo).
+    sharded   : "queries" — ranks own ascending qid ranges, so the concatenation in rank order already IS (qid, tid) order;
+                "index"   — ranks own ascending tid ranges: the concatenation is ordered by (shard, qid, tid).
+    order     : "qid" (default) — for an index-sharded gather one stable device sort on qid restores global (qid, tid) order;
+                "shard" — leave the rank-major concatenation as it is (every block (qid, tid)-ordered; what BASELINE configs[4]
+                asks for: "all-gather of per-shard hit lists").
+    id_counts : (n_queries, n_targets) of the WHOLE job.  With it the rows travel as 64-bit transport words
+                (``ks_hits_pack64_to_device``: ids + both values in one word, rows with wide values on a short escape list):
+                8 bytes per row over the links instead of 20 — the exchange, not the kernels, is the step of an all-vs-all
+                on 8 GPUs.  Without it (or when the ids need more than 48 bits) the four columns travel as they are.
     Returns (qid i32, tid i32, intersect i32, n_weighted i64) torch tensors on `device`, identical on every rank."""
     import torch
     dist = _dist()
@@ -108,6 +115,23 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
         allc = torch.zeros(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allc, mine)
         counts = [int(c) for c in allc.tolist()]
+
+    def own_stream_sync():
+        if on_device and hits._ctx.stream != torch.cuda.current_stream(dev).cuda_stream:
+            hits._ctx.synchronize()  # the copy ran on the context's own stream; the collective runs on torch's
+
+    if world > 1 and id_counts is not None:
+        qbits, tbits = _bits_for(id_counts[0]), _bits_for(id_counts[1])
+        if qbits + tbits <= 48:
+            out = _gather_packed(hits, on_device, n_local, counts, qid_base, tid_base, qbits, tbits, dev, own_stream_sync)
+            if out is not None:
+                qid, tid, isect, nw = out
+                if sharded == "index" and order == "qid" and qid.numel():
+                    idx = torch.sort(qid, stable=True).indices
+                    qid, tid, isect, nw = qid[idx], tid[idx], isect[idx], nw[idx]
+                return qid, tid, isect, nw
+            # (more rows with wide values than the escape list takes: the columns travel unpacked below)
+
     # one block per rank, SoA: qid[cap] | tid[cap] | intersect[cap] | n_weighted[cap] (as 2 x i32 each); with one rank
     # the block is exact, so its columns are the result (no second pass)
     cap = n_local if world == 1 else (max(max(counts), 1) + 63) // 64 * 64
@@ -117,8 +141,7 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
         if on_device:
             base = send.data_ptr()
             hits.copy_to_device(base, base + 4 * cap, base + 8 * cap, base + 12 * cap, qid_base=qid_base, tid_base=tid_base)
-            if hits._ctx.stream != torch.cuda.current_stream(dev).cuda_stream:
-                hits._ctx.synchronize()  # the copy ran on the context's own stream; the collective runs on torch's
+            own_stream_sync()
         else:
             qid, tid, isect, nw = hits
             send[0:n_local] = torch.from_numpy((qid.astype(np.int64) + qid_base).astype(np.int32)).to(dev)
@@ -141,9 +164,63 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
     return qid, tid, isect, nw
 
 
-def all_gather_hits(hits, qid_base: int = 0, tid_base: int = 0, device=None, sharded: str = "queries") -> Hits:
+def _gather_packed(hits, on_device, n_local, counts, qid_base, tid_base, qbits, tbits, dev, own_stream_sync):
+    """The exchange with 64-bit transport words.  Block of a rank (i64 words): packed[cap] | n_esc | esc_row (u32 x esc_cap)
+    | esc_intersect (u32 x esc_cap) | esc_n_weighted (u64 x esc_cap).  None if some rank had more escapes than esc_cap."""
+    import torch
+    dist = _dist()
+    world = len(counts)
+    v = (64 - qbits - tbits) // 2
+    vmax = (1 << v) - 1
+    cap = (max(max(counts), 1) + 63) // 64 * 64
+    esc_cap = max(1024, cap // 64) // 2 * 2
+    words = cap + 1 + 2 * esc_cap  # esc_row + esc_intersect: esc_cap / 2 words each; esc_n_weighted: esc_cap words
+    send = torch.zeros(words, dtype=torch.int64, device=dev)
+    if n_local:
+        if on_device:
+            base = send.data_ptr()
+            hits.pack64_to_device(base, base + 8 * (cap + 1), base + 8 * (cap + 1) + 4 * esc_cap, base + 8 * (cap + 1 + esc_cap),
+                                  base + 8 * cap, esc_cap, qbits, tbits, qid_base=qid_base, tid_base=tid_base)
+            own_stream_sync()
+        else:
+            qid, tid, isect, nw = (np.asarray(x).astype(np.uint64) for x in hits)
+            esc = np.flatnonzero((isect >= vmax) | (nw >= vmax))
+            a, b = isect.copy(), nw.copy()
+            a[esc] = vmax; b[esc] = vmax
+            w = ((((qid + np.uint64(qid_base)) << np.uint64(tbits)) | (tid + np.uint64(tid_base))) << np.uint64(2 * v)) | (a << np.uint64(v)) | b
+            send[:n_local] = torch.from_numpy(w.view(np.int64)).to(dev)
+            send[cap] = len(esc)
+            k = min(len(esc), esc_cap)
+            er = np.zeros(esc_cap, np.uint32); ei = np.zeros(esc_cap, np.uint32); en = np.zeros(esc_cap, np.uint64)
+            er[:k] = esc[:k]; ei[:k] = isect[esc[:k]]; en[:k] = nw[esc[:k]]
+            send[cap + 1:cap + 1 + esc_cap // 2] = torch.from_numpy(er.view(np.int64)).to(dev)
+            send[cap + 1 + esc_cap // 2:cap + 1 + esc_cap] = torch.from_numpy(ei.view(np.int64)).to(dev)
+            send[cap + 1 + esc_cap:] = torch.from_numpy(en.view(np.int64)).to(dev)
+    recv = torch.empty(world * words, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(recv, send)
+    blocks = [recv[r * words:(r + 1) * words] for r in range(world)]
+    n_esc = [int(x) for x in torch.stack([b[cap] for b in blocks]).tolist()]
+    if max(n_esc) > esc_cap:
+        return None
+    w = torch.cat([b[:c] for b, c in zip(blocks, counts)])
+    qid = ((w >> (tbits + 2 * v)) & ((1 << qbits) - 1)).to(torch.int32)
+    tid = ((w >> (2 * v)) & ((1 << tbits) - 1)).to(torch.int32)
+    isect = ((w >> v) & vmax).to(torch.int32)
+    nw = w & vmax
+    off = 0
+    for b, c, ne in zip(blocks, counts, n_esc):
+        if ne:
+            rows = b[cap + 1:cap + 1 + esc_cap // 2].view(torch.int32)[:ne].to(torch.int64) + off
+            isect[rows] = b[cap + 1 + esc_cap // 2:cap + 1 + esc_cap].view(torch.int32)[:ne]
+            nw[rows] = b[cap + 1 + esc_cap:cap + 1 + 2 * esc_cap][:ne]
+        off += c
+    return qid, tid, isect, nw
+
+
+def all_gather_hits(hits, qid_base: int = 0, tid_base: int = 0, device=None, sharded: str = "queries",
+                    id_counts: Optional[Tuple[int, int]] = None) -> Hits:
     """``all_gather_hits_device`` with the result copied to host numpy arrays (qid u32, tid u32, intersect u32, n_weighted u64)."""
-    qid, tid, isect, nw = all_gather_hits_device(hits, qid_base, tid_base, device, sharded)
+    qid, tid, isect, nw = all_gather_hits_device(hits, qid_base, tid_base, device, sharded, id_counts=id_counts)
     return (qid.cpu().numpy().view(np.uint32), tid.cpu().numpy().view(np.uint32), isect.cpu().numpy().view(np.uint32),
             nw.cpu().numpy().view(np.uint64))
 
@@ -152,23 +229,25 @@ SearchFn = Callable[[np.ndarray, np.ndarray, np.ndarray, np.ndarray], Hits]
 
 
 def search_queries_sharded(search_fn: SearchFn, q_res: np.ndarray, q_off: np.ndarray, t_res: np.ndarray,
-                           t_off: np.ndarray, device=None) -> Hits:
+                           t_off: np.ndarray, device=None, packed: bool = True) -> Hits:
     """Every rank holds all targets, takes its residue-balanced share of the queries, searches, and the
     disjoint-by-qid hit lists are concatenated.  search_fn(q_res, q_off, t_res, t_off) -> local COO."""
     rank, world = world_info()
     s0, s1 = shard_by_residues(q_off, world)[rank]
     lq_res, lq_off = slice_batch(q_res, q_off, s0, s1)
-    return all_gather_hits(search_fn(lq_res, lq_off, t_res, t_off), qid_base=s0, device=device, sharded="queries")
+    return all_gather_hits(search_fn(lq_res, lq_off, t_res, t_off), qid_base=s0, device=device, sharded="queries",
+                           id_counts=(len(q_off) - 1, len(t_off) - 1) if packed else None)
 
 
 def search_index_sharded(search_fn: SearchFn, q_res: np.ndarray, q_off: np.ndarray, t_res: np.ndarray,
-                         t_off: np.ndarray, device=None) -> Hits:
+                         t_off: np.ndarray, device=None, packed: bool = True) -> Hits:
     """Every rank holds all queries and indexes its residue-balanced share of the TARGETS; hit lists are
     disjoint by tid and concatenated."""
     rank, world = world_info()
     s0, s1 = shard_by_residues(t_off, world)[rank]
     lt_res, lt_off = slice_batch(t_res, t_off, s0, s1)
-    return all_gather_hits(search_fn(q_res, q_off, lt_res, lt_off), tid_base=s0, device=device, sharded="index")
+    return all_gather_hits(search_fn(q_res, q_off, lt_res, lt_off), tid_base=s0, device=device, sharded="index",
+                           id_counts=(len(q_off) - 1, len(t_off) - 1) if packed else None)
 
 
 def gpu_search_fn(ctx, ksize: int, scaled: int, moltype: str) -> SearchFn:

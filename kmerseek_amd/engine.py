@@ -394,6 +394,14 @@ class Hits(_Owned):
         self._ctx._check(self._ctx._L.ks_hits_copy_to_device(self._ctx._h, self._h, qid_base, tid_base, C.c_void_p(d_qid),
                                                              C.c_void_p(d_tid), C.c_void_p(d_isect), C.c_void_p(d_nw)))
 
+    def pack64_to_device(self, d_packed: int, d_esc_row: int, d_esc_isect: int, d_esc_nw: int, d_n_esc: int, esc_cap: int,
+                         qbits: int, tbits: int, qid_base: int = 0, tid_base: int = 0):
+        """Rows as 64-bit transport words (ks_hits_pack64_to_device) into caller-owned device buffers: 8 instead of 20
+        bytes per row for the all-gather of a multi-GPU search; rows with wide values go to the escape list."""
+        self._ctx._check(self._ctx._L.ks_hits_pack64_to_device(self._ctx._h, self._h, qid_base, tid_base, qbits, tbits,
+                                                               C.c_void_p(d_packed), C.c_void_p(d_esc_row), C.c_void_p(d_esc_isect),
+                                                               C.c_void_p(d_esc_nw), C.c_void_p(d_n_esc), esc_cap))
+
     def to_host(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
         n = self.count
         qid = np.zeros(n, np.uint32); tid = np.zeros(n, np.uint32)

@@ -77,6 +77,60 @@ def test_two_rank_search_equals_single_rank(tmp_path, mode):
         assert np.array_equal(g, w)
 
 
+def _synthetic_hits(rank, n):
+    rng = np.random.default_rng(100 + rank)
+    qid = np.sort(rng.integers(0, 1000, n)).astype(np.uint32)
+    tid = rng.integers(0, 500, n).astype(np.uint32)
+    isect = rng.integers(1, 60, n).astype(np.uint32)
+    nw = isect.astype(np.uint64) + rng.integers(0, 5, n).astype(np.uint64)
+    wide = rng.choice(n, size=max(1, n // 50), replace=False)  # rows whose values do not fit the transport word
+    isect[wide[::2]] = 5000 + rng.integers(0, 1 << 20, len(wide[::2])).astype(np.uint32)
+    nw[wide] = (1 << 40) + rng.integers(0, 1 << 20, len(wide)).astype(np.uint64)
+    return qid, tid, isect, nw
+
+
+def _packed_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from kmerseek_amd import dist as ksd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        h = _synthetic_hits(rank, 3000 + 700 * rank)
+        out = {}
+        # (1M x 1M ids -> 12 value bits: the wide rows take the escape list); second call: escape list too short -> columns unpacked
+        for tag, ids in (("packed", (1 << 20, 1 << 20)), ("plain", None), ("overflow", (1 << 23, 1 << 23))):
+            if tag == "overflow":  # 9 value bits: every row with intersect >= 511 escapes... make most rows wide
+                h2 = (h[0], h[1], h[2] + np.uint32(600), h[3] + np.uint64(600))
+                got = ksd.all_gather_hits(h2, qid_base=rank * 1000, tid_base=7, id_counts=ids)
+            else:
+                got = ksd.all_gather_hits(h, qid_base=rank * 1000, tid_base=7, id_counts=ids)
+            for name, col in zip(("qid", "tid", "isect", "nw"), got):
+                out[f"{tag}_{name}"] = col
+        np.savez(os.path.join(out_dir, f"packed_{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_packed_transport_words_and_escape_list(tmp_path):
+    """The 64-bit transport word of the hit exchange (8 instead of 20 bytes per row over the links): same rows as the
+    unpacked columns, including rows whose values take the escape list and the case where the list is too short."""
+    world = 2
+    mp.spawn(_packed_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "packed_0.npz"), np.load(tmp_path / "packed_1.npz")
+    want = [np.concatenate([_synthetic_hits(r, 3000 + 700 * r)[c] for r in range(world)]) for c in range(4)]
+    want[0] = want[0] + np.repeat(np.arange(world, dtype=np.uint32) * 1000, [3000, 3700])
+    want[1] = want[1] + np.uint32(7)
+    for r in (r0, r1):
+        for tag in ("packed", "plain"):
+            for name, w in zip(("qid", "tid", "isect", "nw"), want):
+                assert np.array_equal(r[f"{tag}_{name}"], w), (tag, name)
+        assert np.array_equal(r["overflow_isect"], want[2] + np.uint32(600)) and np.array_equal(r["overflow_nw"], want[3] + np.uint64(600))
+        assert np.array_equal(r["overflow_qid"], want[0])
+    assert (want[3] > (1 << 39)).sum() > 50
+
+
 def test_shard_by_residues_balances_and_covers():
     from kmerseek_amd import dist as ksd
     rng = np.random.default_rng(0)

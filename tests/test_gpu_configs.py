@@ -133,3 +133,29 @@ def test_dist_layer_single_rank_gpu(ctx):
     assert np.array_equal(got[3].cpu().numpy().view(np.uint64), want[3])
     ptrs = h.device_ptrs()
     assert all(p != 0 for p in ptrs)
+    # transport words of the multi-GPU exchange (8 instead of 20 bytes per row): packed on the device, unpacked as
+    # dist._gather_packed does, rows with wide values through the escape list
+    n = h.count
+    for qbits, tbits in ((10, 10), (20, 20), (24, 24)):
+        v = (64 - qbits - tbits) // 2
+        vmax = (1 << v) - 1
+        esc_cap = 4096
+        buf = torch.zeros(n + 1 + 2 * esc_cap, dtype=torch.int64, device=dev)
+        base = buf.data_ptr()
+        h.pack64_to_device(base, base + 8 * (n + 1), base + 8 * (n + 1) + 4 * esc_cap, base + 8 * (n + 1 + esc_cap), base + 8 * n,
+                           esc_cap, qbits, tbits, qid_base=7, tid_base=9)
+        ctx.synchronize()
+        w = buf[:n]
+        ne = int(buf[n])
+        isect = ((w >> v) & vmax).cpu().numpy().astype(np.uint64)
+        nw = (w & vmax).cpu().numpy().astype(np.uint64)
+        if ne:
+            assert ne <= esc_cap
+            rows = buf[n + 1:n + 1 + esc_cap // 2].view(torch.int32)[:ne].cpu().numpy().astype(np.int64)
+            isect[rows] = buf[n + 1 + esc_cap // 2:n + 1 + esc_cap].view(torch.int32)[:ne].cpu().numpy().view(np.uint32)
+            nw[rows] = buf[n + 1 + esc_cap:n + 1 + 2 * esc_cap][:ne].cpu().numpy().view(np.uint64)
+        assert ne == int(((want[2] >= vmax) | (want[3] >= vmax)).sum())
+        assert np.array_equal(((w >> (tbits + 2 * v)) & ((1 << qbits) - 1)).cpu().numpy(), want[0].astype(np.int64) + 7)
+        assert np.array_equal(((w >> (2 * v)) & ((1 << tbits) - 1)).cpu().numpy(), want[1].astype(np.int64) + 9)
+        assert np.array_equal(isect, want[2].astype(np.uint64)) and np.array_equal(nw, want[3])
+    assert int(want[2].max()) >= 255  # (24 + 24 id bits leave 8 value bits: the related pairs escape)
