@@ -273,6 +273,7 @@ int ks_scan_u32_inplace(ks_ctx *ctx, u32 *data, u64 n, u32 *d_total) {
 #endif
 #define RS_TILE (RS_THREADS * RS_IPT) // 8192 records: ~32 per digit, so digits leave the tile as >= 128-B runs
 #define RS_WAVES (RS_THREADS / 64)
+#define BKS_NB 512 // most high digits of the histogram-free bucket scatter (join prefixes of up to 8 + 9 bits)
 
 // Input geometry of a pass.  Dense: tile b covers records [b*RS_TILE, ...) of n.  Segmented (seg_len != NULL): the
 // input is a set of fixed-capacity regions (region r holds seg_len[r] records from r*seg_cap on) and tile b is the
@@ -429,9 +430,9 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
                                                                         int shift, const u32 *seg_len, u64 seg_cap,
                                                                         u32 tiles_per_seg, u32 *bcur, u32 bcap,
                                                                         unsigned long long *status, u32 pfxK, u32 n_hi, u32 sub_shift) {
-    __shared__ u32 cnt[256];
-    __shared__ u32 dstart[256];
-    __shared__ u32 gbase[256];
+    __shared__ u32 cnt[BKS_NB];     // the high digit takes up to BKS_NB values (n_hi of them in use: a power of two)
+    __shared__ u32 dstart[BKS_NB];
+    __shared__ u32 gbase[BKS_NB];
     __shared__ u32 scan_smem[RS_WAVES + 1];
     __shared__ __attribute__((aligned(16))) u64 stage[RS_TILE];
 
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
     }
     if (nvalid == 0) return; // tile beyond the region's fill (uniform per block)
     const u32 region = (bid / tiles_per_seg) >> sub_shift;
-    if (tid < 256) cnt[tid] = 0;
+    if (tid < BKS_NB) cnt[tid] = 0;
     u64 key[RS_IPT];
     u32 val[RS_IPT];
     u32 rank[RS_IPT]; // (digit << 16) | rank within (tile, digit); 0xffffffff = no record
@@ -464,16 +465,16 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
         const u32 li = (u32)r * RS_THREADS + tid;
         rank[r] = 0xffffffffu;
         if (li < nvalid) {
-            const u32 d = ks_rs_digit(key[r], shift, pfxK);
+            const u32 d = (ks_join_prefix(key[r], pfxK) >> shift) & (n_hi - 1u);
             rank[r] = (d << 16) | atomicAdd(&cnt[d], 1u);
         }
     }
     __syncthreads();
     {
-        const u32 c = tid < 256 ? cnt[tid] : 0u;
+        const u32 c = tid < BKS_NB ? cnt[tid] : 0u;
         u32 total;
         const u32 ds = ks_block_excl_scan(c, scan_smem, &total);
-        if (tid < 256) {
+        if (tid < BKS_NB) {
             dstart[tid] = ds;
             u32 base = 0;
             if (c) {
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
         gdst[i] = ~0ULL;
         if (p < nvalid) {
             const u64 k = stage[p];
-            const u32 d = ks_rs_digit(k, shift, pfxK);
+            const u32 d = (ks_join_prefix(k, pfxK) >> shift) & (n_hi - 1u);
             const u32 slot = gbase[d] + (p - dstart[d]);
             if (slot < bcap) {
                 gdst[i] = (u64)KS_BSLOT(d, region, n_hi) * bcap + slot;

@@ -176,8 +176,10 @@ static int bits_for(u32 n) { // bits needed to represent ids 0..n-1
 }
 
 int ks_join_pbits(u64 n_postings) { // buckets of ~3k index postings; the query side is partitioned on the same bits
+    // (8 bits by the sketch kernel + up to 9 by the bucket scatter; KS_DEBUG_PBITS_MAX is a tuning aid)
+    static const int cap = [] { const char *f = getenv("KS_DEBUG_PBITS_MAX"); const int v = f ? atoi(f) : 16; return v < 1 ? 1 : (v > 17 ? 17 : v); }();
     int pbits = 0;
-    while (pbits < 16 && (n_postings >> pbits) > 3072) pbits++;
+    while (pbits < cap && (n_postings >> pbits) > 3072) pbits++;
     return pbits;
 }
 
@@ -609,10 +611,11 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qk1, (size_t)n_q));
                 SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qv1, (size_t)n_q));
                 if (pre) {
-                    // the sketch kernel did the low digit; one segmented (histogram + scan) pass on the high bits finishes
-                    const int shifts[1] = {8}; // bits [8, 16) of the join prefix
+                    // the sketch kernel did the low digit; segmented (histogram + scan) passes on the high bits finish
+                    int shifts[2], nsh = 0;
+                    for (int sh = 8; sh < pbits; sh += 8) shifts[nsh++] = sh; // bits [8, pbits) of the join prefix
                     ks_rs_segments seg{q->part_len, q->part_cap, q->part_regions << q->part_sub_shift, q->part_sub_shift};
-                    SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_QPART, q->part_keys, q->part_vals, qk1, qv1, qk0, qv0, n_q, shifts, 1,
+                    SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_QPART, q->part_keys, q->part_vals, qk1, qv1, qk0, qv0, n_q, shifts, nsh,
                                                &qk, &qv, &seg, pfxK));
                 } else {
                     ks_timer_begin(ctx, "fill_query_vals");
@@ -621,7 +624,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                     SE_HIP(hipGetLastError());
                     // hashes are read straight from the query sketches on the first pass (no staging copy);
                     // qv0 holds the input qids, so the first pass lands in (qk1, qv1)
-                    int shifts[2], ns = 0;
+                    int shifts[3], ns = 0;
                     for (int sh = 0; sh < pbits; sh += 8) shifts[ns++] = sh; // digits of the join prefix, low first
                     SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_QPART, q->d_hashes, qv0, qk1, qv1, qk0, qv0, n_q, shifts, ns, &qk, &qv,
                                                nullptr, pfxK));
