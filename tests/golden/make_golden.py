@@ -237,7 +237,11 @@ def golden_search():
 
 
 def copy_inputs():
-    for rel in ("fasta/ced9.fasta", "fasta/" + BCL2, "fasta/test_compression.fasta", "fasta/test_compression.fasta.zst"):
+    # (the two larger UniProt downloads are the inputs of the reference's CLI benchmarks, scripts/benchmark_cli.sh:13-15,
+    # benches/benchmark_cli.rs: real length distribution, real low-complexity regions, 'X' residues)
+    for rel in ("fasta/ced9.fasta", "fasta/" + BCL2, "fasta/test_compression.fasta", "fasta/test_compression.fasta.zst",
+                "fasta/uniprotkb_BCL2_AND_model_organism_9606_2025_02_06.fasta.gz",
+                "fasta/uniprotkb_protein_name_Uncharacterized_2025_04_15.fasta.gz"):
         dst = os.path.join(OUT, os.path.basename(rel))
         shutil.copyfile(os.path.join(TD, rel), dst)
         os.chmod(dst, 0o644)
