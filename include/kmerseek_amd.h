@@ -98,6 +98,9 @@ int ks_ctx_pool_stats(const ks_ctx *ctx, uint64_t *n_blocks, uint64_t *bytes_hel
  * out[2] = batches repeated with plain tiles because a compacting tile (scaled > 1) kept more hashes than its LDS lists take,
  * out[3] = batches repeated with window-count sized outputs because they kept more hashes than the expected 1/scaled. */
 int ks_ctx_sketch_stats(const ks_ctx *ctx, uint64_t out[4]);
+/* The same for ks_search: out[0] = searches that ran their join twice because the match list outgrew its first guess
+ * (the list is sized from the previous search of the context), out[1] = reserved (0). */
+int ks_ctx_search_stats(const ks_ctx *ctx, uint64_t out[2]);
 
 /* Plain device buffers for callers that have no HIP binding of their own (the *_device entry points take raw
  * device pointers): 256-byte aligned allocations on ctx's device, stream-ordered copies that return when done. */

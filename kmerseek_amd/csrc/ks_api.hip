@@ -223,6 +223,9 @@ extern "C" void ks_index_free(ks_index *ix) {
     ks_pool_free(ix->ctx, ix->d_keys);
     ks_pool_free(ix->ctx, ix->d_tids);
     ks_pool_free(ix->ctx, ix->d_abunds);
+    ks_pool_free(ix->ctx, ix->d_fp);
+    ks_pool_free(ix->ctx, ix->d_post);
+    ks_pool_free(ix->ctx, ix->d_bmeta);
     ks_pool_free(ix->ctx, ix->d_dir);
     delete ix;
 }

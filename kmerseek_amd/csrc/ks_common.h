@@ -53,7 +53,7 @@ struct ks_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> t_free;
     bool t_open = false; // the last ks_timer_begin recorded a start event
     // small pinned host scratch for counters read back from the device
-    u64 *h_pin = nullptr; // 64 x u64
+    u64 *h_pin = nullptr; // 128 x u64
     // matched posting pairs of recent searches (+ slack): sizes the next search's match list so the join runs once
     u64 pair_cap_hint = 0;
     // hit rows of recent searches (+ slack): sizes the next search's row arrays so that the row count can be read with the
@@ -65,6 +65,7 @@ struct ks_ctx {
     // how often a sketch batch had to be repeated: look-back gave up (-> ticket ids from then on), a compacting tile
     // overflowed its LDS lists (-> plain tiles for that batch), bounded outputs too small (-> window-count sized)
     u64 sketch_ticket_fallbacks = 0, sketch_compact_fallbacks = 0, sketch_cap_fallbacks = 0;
+    u64 join_retries = 0; // searches whose match list outgrew a segment and ran the join twice
     // single-launch scans (ks_prims.hip): status ring + ticket counter in device memory, never reset: every entry is
     // tagged with the global tile number that wrote it
     unsigned long long *scan_ring = nullptr;
@@ -140,14 +141,35 @@ struct ks_sketches {
     u32 part_sub_shift;
 };
 
+// one index posting as the join fetches it for a candidate match: one 16-byte load
+struct __attribute__((aligned(16))) ks_post {
+    u64 key;
+    u32 tid;
+    u32 abund;
+};
+
+// per join bucket: first key (the fingerprints count from it) and the multiplier of the in-LDS directory slot
+// (floor(2^32 * JN_DIR / (largest fingerprint of the bucket + 1)), ks_search.hip)
+struct __attribute__((aligned(16))) ks_bmeta {
+    u64 base;
+    u32 slot_mul;
+    u32 pad;
+};
+
 struct ks_index {
     ks_ctx *ctx;
     ks_params params;
     u32 n_targets;
     u64 n_postings;
-    u64 *d_keys;   // sorted hashes
-    u32 *d_tids;   // target id per posting
-    u32 *d_abunds; // target abundance per posting
+    u64 *d_keys;   // sorted hashes      } columns of the sort: what the join of a small / medium index reads;
+    u32 *d_tids;   // target id          } released once d_fp / d_post are written when the index is big (fp_layout)
+    u32 *d_abunds; // target abundance   }
+    u32 *d_fp;     // per posting, in hash order: min((key - first key of its join bucket) >> (32 - pbits), 2^32 - 1) — the 4 bytes
+                   // per posting the join streams; monotone inside a bucket
+    ks_post *d_post; // per posting, in hash order: (key, tid, abundance)
+    ks_bmeta *d_bmeta; // per join bucket (2^pbits entries)
+    bool fp_layout;    // true: d_fp / d_post / d_bmeta are what the join reads; false: the sorted columns
+    int fp_shift;      // 32 - pbits (KS_DEBUG_FP_COARSEN adds to it: coarser fingerprints, more false candidates — tests)
     u32 max_abund; // largest of them: how many low bits of a packed match record the abundance needs
     u64 *d_dir;    // join-bucket directory: d_dir[b] = first posting whose join prefix is >= b (2^pbits + 1 entries)
     int pbits;     // join prefix bits, a function of n_postings alone (ks_join_pbits)

@@ -113,7 +113,7 @@ extern "C" int ks_ctx_create(int device, void *hip_stream, ks_ctx **out) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
         ctx->own_stream = true;
     }
-    if (hipHostMalloc((void **)&ctx->h_pin, 64 * sizeof(u64)) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
+    if (hipHostMalloc((void **)&ctx->h_pin, 128 * sizeof(u64)) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
     if (hipMalloc((void **)&ctx->d_lut, 3 * 256) != hipSuccess) { delete ctx; return KS_ERR_OOM; }
     u8 lut[768];
     build_luts(lut);
@@ -162,6 +162,12 @@ extern "C" int ks_ctx_sketch_stats(const ks_ctx *ctx, uint64_t out[4]) {
     if (!ctx || !out) return KS_ERR_INVALID_ARG;
     out[0] = ctx->sketch_ticket_fallbacks; out[1] = ctx->sketch_use_ticket ? 1 : 0;
     out[2] = ctx->sketch_compact_fallbacks; out[3] = ctx->sketch_cap_fallbacks;
+    return KS_OK;
+}
+
+extern "C" int ks_ctx_search_stats(const ks_ctx *ctx, uint64_t out[2]) {
+    if (!ctx || !out) return KS_ERR_INVALID_ARG;
+    out[0] = ctx->join_retries; out[1] = 0;
     return KS_OK;
 }
 

@@ -48,6 +48,11 @@ __global__ __launch_bounds__(256) void k_split_vals(const u64 *vals, u64 n, u32 
 
 int ks_join_pbits(u64 n_postings);
 __global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int pbits, u32 pfxK, u64 *dir);
+__global__ __launch_bounds__(256) void k_index_finish(const u64 *keys, const u32 *tids, const u32 *abunds, const u64 *dir, u64 n, int pbits,
+                                                      u32 pfxK, int fp_shift, u32 *fp, ks_post *post);
+__global__ __launch_bounds__(256) void k_index_bmeta(const u64 *keys, const u64 *dir, u32 n_buckets, int fp_shift, ks_bmeta *bmeta);
+
+#define JN_FP_PBITS 15 // indexes with this many join-prefix bits or more (> 50M postings) use the fingerprint layout (see the join)
 
 int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
     if (!t || !out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
@@ -112,16 +117,43 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
         // the join-bucket directory belongs to the index (its prefix width depends on the posting count alone)
         ix->pbits = ks_join_pbits(n);
         const u32 nb = 1u << ix->pbits;
+        const u32 K = ks_join_prefix_mul(ix->pbits, ks_max_hash(t->params.scaled));
         IX_CHECK(ks_alloc(ctx, &ix->d_dir, (size_t)nb + 1));
         ks_timer_begin(ctx, "bucket_dir");
-        hipLaunchKernelGGL(k_bucket_dir, dim3((nb + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys, n, ix->pbits,
-                           ks_join_prefix_mul(ix->pbits, ks_max_hash(t->params.scaled)), ix->d_dir);
+        hipLaunchKernelGGL(k_bucket_dir, dim3((nb + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys, n, ix->pbits, K, ix->d_dir);
         ks_timer_end(ctx);
         IX_HIP(hipGetLastError());
+        // Big indexes (>= 2^JN_FP_PBITS join buckets) are joined on 4-byte fingerprints (streamed) + 16-byte postings (fetched per
+        // candidate match); the others keep the sorted columns (k_join_buckets_keys)
+        ix->fp_layout = ix->pbits >= JN_FP_PBITS || getenv("KS_DEBUG_JOIN_FP");
+        if (ix->fp_layout) {
+        IX_CHECK(ks_alloc(ctx, &ix->d_fp, (size_t)(n ? n : 1)));
+        IX_CHECK(ks_alloc(ctx, &ix->d_post, (size_t)(n ? n : 1)));
+        ix->fp_shift = 32 - ix->pbits;
+        if (getenv("KS_DEBUG_FP_COARSEN")) {
+            ix->fp_shift += atoi(getenv("KS_DEBUG_FP_COARSEN"));
+            if (ix->fp_shift > 63) ix->fp_shift = 63;
+        }
+        IX_CHECK(ks_alloc(ctx, &ix->d_bmeta, (size_t)nb));
+        hipLaunchKernelGGL(k_index_bmeta, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys, (const u64 *)ix->d_dir,
+                           nb, ix->fp_shift, ix->d_bmeta);
+        IX_HIP(hipGetLastError());
+        if (n > 0) {
+            ks_timer_begin(ctx, "index_finish");
+            hipLaunchKernelGGL(k_index_finish, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys,
+                               (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds, (const u64 *)ix->d_dir, n, ix->pbits, K, ix->fp_shift, ix->d_fp, ix->d_post);
+            ks_timer_end(ctx);
+            IX_HIP(hipGetLastError());
+        }
+        }
     }
     IX_CHECK(ks_scan_status_fetch(ctx));
     IX_HIP(hipStreamSynchronize(ctx->stream));
     IX_CHECK(ks_scan_status_check(ctx));
+    if (ix->fp_layout) { // the sorted columns were the input of the finish pass only
+        ks_pool_free(ctx, ix->d_keys); ks_pool_free(ctx, ix->d_tids); ks_pool_free(ctx, ix->d_abunds);
+        ix->d_keys = nullptr; ix->d_tids = nullptr; ix->d_abunds = nullptr;
+    }
 done:
     ks_pool_free(ctx, k0); ks_pool_free(ctx, k1); ks_pool_free(ctx, v0); ks_pool_free(ctx, v1); ks_pool_free(ctx, d_max);
     if (st != KS_OK) { (void)hipStreamSynchronize(ctx->stream); ks_index_free(ix); return st; }
@@ -214,11 +246,15 @@ __global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int 
     dir[b] = lo;
 }
 
+// ---- the join of small and medium indexes (fewer than 2^JN_FP_PBITS buckets): full 64-bit keys staged in LDS, one cursor.
+// With few buckets there is little to gain from a narrower stream, and searches that match most of their queries
+// (all-vs-all) are better off without the confirmation fetches of the fingerprint kernel below.
+#define JN_CAP_KEYS 6144 // 48 KiB of LDS -> 3 workgroups (24 waves) per CU
 // number of staged keys < h.  Branchless halving on the ACTUAL bucket size: the trip count ceil(log2 n) is uniform
 // across the workgroup, and the probe positions are multiples of n/2, n/4, ... rather than of powers of two —
 // power-of-two probe strides put every lane of a wave on ONE LDS bank (measured: 86 % of the LDS cycles of this
 // kernel were bank-conflict cycles with the 4096/2048/... ladder).
-KS_DEV u32 jn_lower_bound_lds(const u64 *lk, u32 n, u64 h) {
+KS_DEV u32 jn_lower_bound_keys(const u64 *lk, u32 n, u64 h) {
     u32 base = 0, len = n;
     while (len > 1) { // uniform: n is the same for every lane
         const u32 half = len >> 1;
@@ -231,12 +267,12 @@ KS_DEV u32 jn_lower_bound_lds(const u64 *lk, u32 n, u64 h) {
 // cursor[0] = matches appended so far (keeps counting past `cap` so the host can size a retry).
 // Per round of JN_THREADS*JN_E query postings: search once, keep (position, run length) in registers,
 // reserve the round's slice of the pair list with ONE device-wide atomic, then write from registers.
-__global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, const u32 *qids, const u64 *ikeys,
+__global__ __launch_bounds__(JN_THREADS) void k_join_buckets_keys(const u64 *qkeys, const u32 *qids, const u64 *ikeys,
                                                              const u32 *itids, const u32 *iabunds, const u64 *q_lo,
                                                              const u64 *q_hi, const u64 *dir_t, u64 *pair_keys,
                                                              u32 *pair_vals, u64 cap, unsigned long long *cursor,
                                                              int tbits, int abits) {
-    __shared__ u64 lk[JN_CAP];
+    __shared__ u64 lk[JN_CAP_KEYS];
     __shared__ u32 wlist[JN_THREADS / 64][JN_WLIST]; // per-wave list of the round's pairs (query | index posting << 13)
     __shared__ u32 scan_smem[JN_THREADS / 64 + 1];
     __shared__ unsigned long long base_s;
@@ -244,8 +280,8 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
     const u64 qs = q_lo[blockIdx.x], qe = q_hi[blockIdx.x]; // dense postings: q_hi = q_lo + 1 (a directory)
     const u64 ts = dir_t[blockIdx.x], te = dir_t[blockIdx.x + 1];
     if (qs == qe || ts == te) return;
-    for (u64 c0 = ts; c0 < te; c0 += JN_CAP) {
-        const u32 n = (u32)((te - c0) < JN_CAP ? (te - c0) : JN_CAP);
+    for (u64 c0 = ts; c0 < te; c0 += JN_CAP_KEYS) {
+        const u32 n = (u32)((te - c0) < JN_CAP_KEYS ? (te - c0) : JN_CAP_KEYS);
         // JN_FILLU loads of a thread are in flight before their LDS stores (a plain loop waits out one memory latency
         // per 512 keys; all JN_CAP / JN_THREADS at once costs the registers of a third workgroup per CU)
         for (u32 i0 = 0; i0 < n; i0 += JN_THREADS * JN_FILLU) {
@@ -278,7 +314,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
                 // (uniform: a bucket with few query postings — small batches, query shards of a strong-scaling run — fills
                 // only the first slots of the round, and an empty slot would cost the same 13 LDS probes as a full one)
                 if (q0 + (u64)e * JN_THREADS >= qe) continue;
-                u32 lo = jn_lower_bound_lds(lk, n, h[e]);
+                u32 lo = jn_lower_bound_keys(lk, n, h[e]);
                 u32 c = 0;
                 if (i < qe)
                     while (lo + c < n && lk[lo + c] == h[e]) c++;
@@ -347,6 +383,362 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets(const u64 *qkeys, c
             }
         }
         __syncthreads();
+    }
+}
+
+// ---- the join of big indexes: 32-bit fingerprints streamed, candidates confirmed on 16-byte postings
+// Fingerprint of a key inside its join bucket (first key `base`): monotone in the key, 32 bits.  A bucket spans at most
+// 2^(64 - pbits) hash values, so with shift = 32 - pbits the clamp never bites for scaled = 1; it keeps the function total
+// (and monotone) whatever the prefix rounding does for other `scaled`.  Equal fingerprints are CANDIDATES: the join confirms
+// them on the full key.
+KS_DEV u32 jn_fingerprint(u64 key, u64 base, int shift) {
+    const u64 f = (key - base) >> shift;
+    return f > 0xffffffffULL ? 0xffffffffu : (u32)f;
+}
+
+__global__ __launch_bounds__(256) void k_index_finish(const u64 *keys, const u32 *tids, const u32 *abunds, const u64 *dir, u64 n, int pbits,
+                                                      u32 pfxK, int fp_shift, u32 *fp, ks_post *post) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 key = keys[i];
+    const u32 b = pbits ? ks_join_prefix(key, pfxK) : 0u;
+    const u64 base = keys[dir[b]]; // (the same two cached words for the ~4k consecutive postings of a bucket)
+    fp[i] = jn_fingerprint(key, base, fp_shift);
+    ks_post p;
+    p.key = key; p.tid = tids[i]; p.abund = abunds[i];
+    post[i] = p;
+}
+
+#ifndef JN_DIR
+#define JN_DIR 2048
+#endif
+#define JN_SEGS 64       // most segments (cursors) of the pair list
+#define JN_CUR_STRIDE 64 // u64 words between two cursors
+// Diagnostic build only (-DJN_STAMP): per-phase shader-clock shares of k_join_buckets, summed over workgroups by thread 0
+// (tools/microbench.py --variants JN_STAMP).  Never compiled into the shipped library.
+#ifdef JN_STAMP
+#define JN_STAMP_SLOTS 4096
+__device__ unsigned long long jn_stamp_acc[JN_STAMP_SLOTS][16];
+#define JN_STAMP_AT(i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); \
+    atomicAdd(&jn_stamp_acc[blockIdx.x % JN_STAMP_SLOTS][i], t_ - jn_t_prev); jn_t_prev = clock64(); } } while (0)
+extern "C" void ks_debug_read_join_stamps(unsigned long long *out, int reset) {
+    static unsigned long long host[JN_STAMP_SLOTS][16];
+    (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(jn_stamp_acc), sizeof host);
+    for (int i = 0; i < 16; i++) { out[i] = 0; for (int s = 0; s < JN_STAMP_SLOTS; s++) out[i] += host[s][i]; }
+    if (reset) { memset(host, 0, sizeof host); (void)hipMemcpyToSymbol(HIP_SYMBOL(jn_stamp_acc), host, sizeof host); }
+}
+#else
+#define JN_STAMP_AT(i) do { } while (0)
+#endif
+// directory slot of a fingerprint: floor(f * JN_DIR / (largest staged fingerprint + 1)), capped; monotone in f
+KS_DEV u32 jn_slot_mul(u32 largest) {
+    const u64 m = ((u64)JN_DIR << 32) / ((u64)largest + 1ULL);
+    return m > 0xffffffffULL ? 0xffffffffu : (u32)m;
+}
+KS_DEV u32 jn_slot(u32 f, u32 mul) {
+    const u32 j = __umulhi(f, mul);
+    return j < (u32)JN_DIR - 1u ? j : (u32)JN_DIR - 1u;
+}
+
+// per join bucket: what the join kernel needs besides the directory words
+__global__ __launch_bounds__(256) void k_index_bmeta(const u64 *keys, const u64 *dir, u32 n_buckets, int fp_shift, ks_bmeta *bmeta) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_buckets) return;
+    const u64 ts = dir[b], te = dir[b + 1];
+    ks_bmeta m;
+    m.base = 0; m.slot_mul = 0; m.pad = 0;
+    if (ts < te) {
+        m.base = keys[ts];
+        m.slot_mul = jn_slot_mul(jn_fingerprint(keys[te - 1], m.base, fp_shift));
+    }
+    bmeta[b] = m;
+}
+
+// number of staged fingerprints < f.  Branchless halving on the ACTUAL bucket size: the trip count ceil(log2 n) is uniform
+// across the workgroup, and the probe positions are multiples of n/2, n/4, ... rather than of powers of two —
+// power-of-two probe strides put every lane of a wave on ONE LDS bank (measured: 86 % of the LDS cycles of this
+// kernel were bank-conflict cycles with the 4096/2048/... ladder).
+KS_DEV u32 jn_lower_bound_lds(const u32 *lk, u32 n, u32 f) {
+    u32 base = 0, len = n;
+    while (len > 1) { // uniform: n is the same for every lane
+        const u32 half = len >> 1;
+        base = (lk[base + half - 1] < f) ? base + half : base;
+        len -= half;
+    }
+    return base + (lk[base] < f ? 1u : 0u);
+}
+
+// A candidate run [p0, p0 + c) of equal fingerprints, confirmed on the full keys (sorted): the postings whose key IS h.
+// Almost always c == 1 and the key matches; distinct keys under one fingerprint (2^-32-ish per probe) take the searches.
+KS_DEV void jn_confirm_slow(const ks_post *post, u32 p0, u32 c, u64 h, u32 *first, u32 *count) {
+    u32 lo = 0, hi = c; // first key >= h
+    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (post[p0 + m].key < h) lo = m + 1; else hi = m; }
+    u32 lo2 = lo, hi2 = c; // first key > h
+    while (lo2 < hi2) { const u32 m = (lo2 + hi2) >> 1; if (post[p0 + m].key <= h) lo2 = m + 1; else hi2 = m; }
+    *first = lo; *count = lo2 - lo;
+}
+
+// cursor[0] = matches appended so far (keeps counting past `cap` so the host can size a retry).
+// Per round of JN_THREADS*JN_E query postings: every thread searches the staged fingerprints for its queries (LDS only);
+// the candidates of a wave — a few per cent of its queries, anywhere among a thread's JN_E slots — are LISTED in LDS
+// (query slot, index posting, full hash), so that lane k confirms and emits candidate k: one 16-byte posting fetch and one
+// qid fetch per candidate in full lanes, the confirmed ones ranked by a block scan, ONE device-wide atomic reserving the
+// round's slice of the pair list, contiguous stores.
+__global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_join_buckets(
+    const u64 *qkeys, const u32 *qids, const u32 *ifp, const ks_post *ipost, const ks_bmeta *bmeta, const u64 *q_lo, const u64 *q_hi,
+    const u64 *dir_t, u64 *pair_keys, u32 *pair_vals, u64 cap, unsigned long long *cursors, u32 seg_mask, int tbits, int abits,
+    int fp_shift) {
+    __shared__ u32 lk[JN_CAP];
+    __shared__ unsigned short ldir[JN_DIR + 2]; // ldir[j] = staged fingerprints whose slot (jn_slot) is < j
+    __shared__ u32 wlist[JN_THREADS / 64][JN_WLIST]; // per-wave candidate list: query slot | index posting << 13
+    __shared__ u64 wlist_h[JN_THREADS / 64][JN_WLIST]; // ... and the query's hash
+    __shared__ u32 scan_smem[JN_THREADS / 64 + 1];
+    __shared__ unsigned long long base_s;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+#ifdef JN_STAMP
+    unsigned long long jn_t_prev = clock64();
+#endif
+    const u64 qs = q_lo[blockIdx.x], qe = q_hi[blockIdx.x]; // dense postings: q_hi = q_lo + 1 (a directory)
+    const u64 ts = dir_t[blockIdx.x], te = dir_t[blockIdx.x + 1];
+    const ks_bmeta bm = bmeta[blockIdx.x]; // (with the directory words: one memory latency)
+    if (qs == qe || ts == te) return;
+    // The pair list is cut into seg_mask + 1 segments of `cap` records, each with its own cursor (JN_CUR_STRIDE words apart:
+    // different memory channels): atomics on ONE address are served one at a time, ~12 ns each on this chip — 65,536 buckets
+    // on one cursor are 0.8 ms of queueing whatever else the kernel does.  A bucket appends to segment (bucket mod segments).
+    const u32 seg = blockIdx.x & seg_mask;
+    unsigned long long *cursor = cursors + (size_t)seg * JN_CUR_STRIDE;
+    pair_keys += (u64)seg * cap;
+    if (pair_vals) pair_vals += (u64)seg * cap;
+    const u64 kbase = bm.base; // the bucket's first key: the fingerprints count from it
+    const u32 dirM = bm.slot_mul;
+    // The first round's query postings are requested before the fingerprints are staged: the two latencies overlap.
+    u64 h[JN_E];
+    {
+        const u32 nq0 = (u32)((qe - qs) < (u64)JN_THREADS * JN_E ? (qe - qs) : (u64)JN_THREADS * JN_E);
+#pragma unroll
+        for (int e = 0; e < JN_E; e++) {
+            const u32 i = (u32)e * JN_THREADS + tid;
+            h[e] = i < nq0 ? qkeys[qs + i] : 0;
+        }
+    }
+    for (u64 c0 = ts; c0 < te; c0 += JN_CAP) {
+        const u32 n = (u32)((te - c0) < JN_CAP ? (te - c0) : JN_CAP);
+        const u32 *fpc = ifp + c0;       // uniform bases + 32-bit lane offsets: scalar base, one VGPR per address
+        const ks_post *postc = ipost + c0;
+        JN_STAMP_AT(0); // directory words + first key
+        // Staging, and in the same pass a DIRECTORY over the staged fingerprints: they are uniform inside the bucket, so slot
+        // j = floor(f * JN_DIR / (the bucket's largest + 1)) holds n / JN_DIR of them on average, and a query's search is two
+        // directory reads and a search of its slot's few entries instead of log2(n) dependent LDS probes.  ldir[j] = staged
+        // fingerprints whose slot is < j: entry j is written by the first fingerprint whose slot is >= j — a thread sees that
+        // from its fingerprint and the one before it (a second, overlapping load).  JN_FILLU of each are in flight before the
+        // LDS stores.
+        {
+            const u32 s_first = jn_slot(fpc[0], dirM), s_last = jn_slot(fpc[n - 1], dirM); // (uniform; slot 0 unless a later chunk)
+            for (u32 j = tid; j <= s_first; j += JN_THREADS) ldir[j] = 0;
+            for (u32 j = s_last + 1u + tid; j <= (u32)JN_DIR; j += JN_THREADS) ldir[j] = (unsigned short)n;
+        }
+        for (u32 i0 = 0; i0 < n; i0 += JN_THREADS * JN_FILLU) {
+            u32 kk[JN_FILLU], pp[JN_FILLU];
+#pragma unroll
+            for (int j = 0; j < JN_FILLU; j++) {
+                const u32 i = i0 + (u32)j * JN_THREADS + tid;
+                kk[j] = i < n ? fpc[i] : 0;
+                pp[j] = (i < n && i) ? fpc[i - 1] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < JN_FILLU; j++) {
+                const u32 i = i0 + (u32)j * JN_THREADS + tid;
+                if (i < n) {
+                    lk[i] = kk[j];
+                    if (i) {
+                        const u32 sa = jn_slot(kk[j], dirM);
+                        for (u32 sl = jn_slot(pp[j], dirM) + 1u; sl <= sa; sl++) ldir[sl] = (unsigned short)i;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        JN_STAMP_AT(1); // fingerprints staged, directory built
+        for (u64 q0 = qs; q0 < qe; q0 += (u64)JN_THREADS * JN_E) {
+            u32 info[JN_E]; // position | run length << 16
+            const u64 *qkr = qkeys + q0;
+            const u32 *qir = qids + q0;
+            const u32 nq = (u32)((qe - q0) < (u64)JN_THREADS * JN_E ? (qe - q0) : (u64)JN_THREADS * JN_E); // query postings of this round
+            if (q0 != qs || c0 != ts) { // (uniform; the first round's are on their way since the top)
+#pragma unroll
+                for (int e = 0; e < JN_E; e++) {
+                    const u32 i = (u32)e * JN_THREADS + tid;
+                    h[e] = i < nq ? qkr[i] : 0;
+                }
+            }
+#ifdef JN_STAMP
+            if (tid == 0 && h[0] == 0x123456789abcdefULL) jn_t_prev++; // (waits for the loads)
+#endif
+            JN_STAMP_AT(3); // query postings loaded
+            u32 cand = 0, mine = 0; // cand: bit e set = query e of this thread has candidates; mine: how many postings
+#pragma unroll
+            for (int e = 0; e < JN_E; e++) {
+                const u32 i = (u32)e * JN_THREADS + tid;
+                info[e] = 0;
+                // (uniform: a bucket with few query postings — small batches, query shards of a strong-scaling run — fills
+                // only the first slots of the round, and an empty slot would cost the same 13 LDS probes as a full one)
+                if ((u32)e * JN_THREADS >= nq) continue;
+                const u32 f = jn_fingerprint(h[e], kbase, fp_shift);
+                const u32 sl = jn_slot(f, dirM);
+                const u32 d0 = ldir[sl], d1 = ldir[sl + 1];
+                // the slot holds n / JN_DIR fingerprints on average — none or one, mostly: look at them all; a slot crowded by
+                // repeats of one hash is searched
+                u32 lo = d0, c = 0;
+                if (i < nq && h[e] >= kbase) { // (a hash below the bucket's first key matches nothing)
+                    if (d1 - d0 <= 8u) {
+                        for (u32 r = d0; r < d1; r++)
+                            if (lk[r] == f) { lo = c ? lo : r; c++; }
+                    } else {
+                        lo = d0 + jn_lower_bound_lds(lk + d0, d1 - d0, f);
+                        while (lo + c < d1 && lk[lo + c] == f) c++;
+                    }
+                }
+                info[e] = lo | (c << 16);
+                mine += c;
+                cand |= c ? (1u << e) : 0u;
+            }
+            JN_STAMP_AT(4); // searched
+            const u32 wincl = ks_wave_incl_scan(mine);
+            const u32 wtotal = __shfl(wincl, 63, 64); // candidates of this wave
+            u32 conf = 0;                             // confirmed pairs this lane will write
+            u64 rk[JN_WLIST / 64];
+            u32 rv[JN_WLIST / 64], okm = 0; // okm: bit it set = slot it of this lane holds a confirmed pair
+            if (wtotal <= JN_WLIST) { // uniform per wave
+                u32 p = wincl - mine;
+                while (cand) {
+                    const int e = __builtin_ctz(cand);
+                    cand &= cand - 1;
+                    u32 inf = info[0];
+                    u64 he = h[0];
+#pragma unroll
+                    for (int k = 1; k < JN_E; k++) { inf = e == k ? info[k] : inf; he = e == k ? h[k] : he; } // (register arrays: select, no indexing)
+                    const u32 c = inf >> 16, qi = (u32)e * JN_THREADS + tid, pos = inf & 0xffffu;
+                    for (u32 j = 0; j < c; j++, p++) {
+                        wlist[wave][p] = qi | ((pos + j) << 13); wlist_h[wave][p] = he;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier(); // same wave: LDS operations execute in order
+#pragma unroll
+                for (int it = 0; it < JN_WLIST / 64; it++) {
+                    rk[it] = 0; rv[it] = 0;
+                    const u32 k = (u32)it * 64u + lane;
+                    if (k < wtotal) {
+                        const u32 en = wlist[wave][k];
+                        const ks_post pt = postc[en >> 13];
+                        const u32 q = qir[en & 0x1fffu];
+                        if (pt.key == wlist_h[wave][k]) { // confirmed
+                            const u64 ids = ((u64)q << tbits) | pt.tid; // ids packed tight: fewer sort passes
+                            rk[it] = pair_vals ? ids : ((ids << abits) | pt.abund); // packed: one 8-byte record per match
+                            rv[it] = pt.abund;
+                            okm |= 1u << it;
+                            conf++;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else { // a hash shared by many targets: confirm whole runs, emit straight from the registers
+#pragma unroll
+                for (int e = 0; e < JN_E; e++) {
+                    if (!((cand >> e) & 1u)) continue;
+                    u32 lo = info[e] & 0xffffu, c = info[e] >> 16;
+                    if (postc[lo].key != h[e] || postc[lo + c - 1].key != h[e]) {
+                        u32 first, cnt;
+                        jn_confirm_slow(postc, lo, c, h[e], &first, &cnt);
+                        lo += first; c = cnt;
+                    }
+                    info[e] = lo | (c << 16);
+                    conf += c;
+                    if (!c) cand &= ~(1u << e);
+                }
+            }
+#ifdef JN_STAMP
+            if (tid == 0 && rk[0] == 0x123456789abcdefULL) jn_t_prev++;
+#endif
+            JN_STAMP_AT(5); // candidates listed, fetched, confirmed
+            // Reserving the round's slice of the pair list.  Segmented list (many buckets): every wave reserves for itself — no
+            // workgroup barrier between the search and the stores, the waves of a bucket run free until the next chunk is
+            // staged (the atomics spread over the segment cursors).  One cursor (few buckets): one atomic per workgroup round.
+            u32 total;
+            u64 slot;
+            if (seg_mask) { // uniform
+                const u32 cincl = ks_wave_incl_scan(conf);
+                total = __shfl(cincl, 63, 64);
+                JN_STAMP_AT(6); // wave scan
+                unsigned long long wb = 0;
+                if (total) { // uniform per wave
+                    if (lane == 0) wb = atomicAdd(cursor, (unsigned long long)total);
+                    wb = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(wb >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)wb);
+                }
+                slot = wb + (cincl - conf);
+            } else {
+                const u32 off = ks_block_excl_scan(conf, scan_smem, &total);
+                JN_STAMP_AT(6); // block scan
+                if (total) { // uniform
+                    if (tid == 0) base_s = atomicAdd(cursor, (unsigned long long)total);
+                    __syncthreads();
+                }
+                slot = base_s + off;
+            }
+            JN_STAMP_AT(7); // slice reserved
+            if (total) {
+                if (wtotal <= JN_WLIST) {
+#pragma unroll
+                    for (int it = 0; it < JN_WLIST / 64; it++) {
+                        if ((okm >> it) & 1u) {
+                            if (slot < cap) {
+                                pair_keys[slot] = rk[it];
+                                if (pair_vals) pair_vals[slot] = rv[it];
+                            }
+                            slot++;
+                        }
+                    }
+                } else {
+                    while (cand) {
+                        const int e = __builtin_ctz(cand);
+                        cand &= cand - 1;
+                        u32 inf = info[0];
+#pragma unroll
+                        for (int k = 1; k < JN_E; k++) inf = e == k ? info[k] : inf;
+                        const u32 c = inf >> 16;
+                        const u32 q = qir[(u32)e * JN_THREADS + tid];
+                        const u32 j0 = inf & 0xffffu;
+                        for (u32 j = 0; j < c; j++, slot++) {
+                            if (slot < cap) {
+                                const ks_post pt = postc[j0 + j];
+                                const u64 ids = ((u64)q << tbits) | pt.tid;
+                                if (pair_vals) { pair_keys[slot] = ids; pair_vals[slot] = pt.abund; }
+                                else pair_keys[slot] = (ids << abits) | pt.abund;
+                            }
+                        }
+                    }
+                }
+                if (!seg_mask) __syncthreads(); // base_s is rewritten next round
+                JN_STAMP_AT(8); // pairs written
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// the segments of the pair list (seg_cap records apart, prefix[s+1] - prefix[s] of them filled) -> one dense list
+struct jn_seg_table { u64 prefix[JN_SEGS + 1]; };
+__global__ __launch_bounds__(256) void k_pairs_compact(const u64 *src_k, const u32 *src_v, u64 seg_cap, jn_seg_table tab, u64 *dst_k, u32 *dst_v) {
+    const u32 s = blockIdx.y;
+    const u64 n = tab.prefix[s + 1] - tab.prefix[s], i0 = (u64)blockIdx.x * 2048;
+    const u64 *sk = src_k + (u64)s * seg_cap;
+    u64 *dk = dst_k + tab.prefix[s];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const u64 i = i0 + (u64)j * 256 + threadIdx.x;
+        if (i < n) {
+            dk[i] = sk[i];
+            if (src_v) dst_v[tab.prefix[s] + i] = src_v[(u64)s * seg_cap + i];
+        }
     }
 }
 
@@ -573,18 +965,22 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         const u32 pfxK = ks_join_prefix_mul(pbits, ks_max_hash(ix->params.scaled));
         SE_CHECK(ks_alloc(ctx, &dir_q, (size_t)2 * n_buckets + 2));
         const u64 *dir_t = ix->d_dir; // built with the index
-        SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, 2)); // [0] matches appended, [1] a query bucket overflowed
+        // cursor block: segment s of the pair list counts at word s * JN_CUR_STRIDE; after the last segment, [+1] = "a query
+        // bucket overflowed" (k_bucket_scatter)
+        SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, (size_t)(JN_SEGS + 1) * JN_CUR_STRIDE));
+        unsigned long long *const flagw = cursor + (size_t)JN_SEGS * JN_CUR_STRIDE;
         const bool pre = q->part_keys && q->part_pbits == pbits && q->part_K == pfxK && pbits > 0;
         u64 cap = n_q < (1u << 20) ? (1u << 20) : n_q;
         if (ctx->pair_cap_hint > cap) cap = ctx->pair_cap_hint; // a workload that matched heavily last time will again
-        u64 n_pairs = 0;
+        u64 n_pairs = 0, seg_cap = 0, seg_count[JN_SEGS];
+        u32 n_segs = 1;
         // way 0: histogram-free bucket scatter of the sketch kernel's regions (may overflow on skewed hashes);
         // way 1: the dense, always-correct partition
         for (int way = (pre && pbits > 8) ? 0 : 1; way < 2; way++) {
             u64 *qk = nullptr;
             u32 *qv = nullptr;
             const u64 *q_lo = nullptr, *q_hi = nullptr;
-            SE_HIP(hipMemsetAsync(cursor, 0, 2 * sizeof(u64), ctx->stream));
+            SE_HIP(hipMemsetAsync(cursor, 0, ((size_t)JN_SEGS * JN_CUR_STRIDE + 2) * sizeof(u64), ctx->stream));
             if (way == 0) {
                 const u64 per = n_q / n_buckets;
                 const u32 bcap = (u32)(per + per / 8 + 512);
@@ -593,7 +989,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 SE_CHECK(ks_alloc(ctx, &bcur, (size_t)n_buckets));
                 SE_HIP(hipMemsetAsync(bcur, 0, (size_t)n_buckets * sizeof(u32), ctx->stream));
                 ks_rs_segments seg{q->part_len, q->part_cap, q->part_regions << q->part_sub_shift, q->part_sub_shift};
-                SE_CHECK(ks_bucket_scatter_u32(ctx, q->part_keys, q->part_vals, &seg, 8, pfxK, qk0, qv0, bcur, bcap, cursor, n_buckets >> 8));
+                SE_CHECK(ks_bucket_scatter_u32(ctx, q->part_keys, q->part_vals, &seg, 8, pfxK, qk0, qv0, bcur, bcap, flagw, n_buckets >> 8));
                 ks_timer_begin(ctx, "bucket_dir");
                 hipLaunchKernelGGL(k_region_dir, dim3((n_buckets + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)bcur, (u64)bcap,
                                    n_buckets, dir_q, dir_q + n_buckets, n_buckets >> 8);
@@ -636,35 +1032,58 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             }
             SE_HIP(hipGetLastError());
 
-            // join, with a retry if the match list outgrows its first guess
+            // join, with a retry if the match list outgrows its first guess.  Many (bucket, round) reservations: the list is cut
+            // into segments with a cursor each (see the kernel) and made dense by one copy afterwards; few: one cursor, no copy.
             bool overflowed = false;
+            {
+                const u64 per_bucket = n_q / n_buckets, round = (u64)JN_THREADS * JN_E;
+                const u64 reservations = (u64)n_buckets * ((per_bucket + round - 1) / round ? (per_bucket + round - 1) / round : 1);
+                n_segs = (ix->fp_layout && reservations >= 8192 && n_buckets >= JN_SEGS && !getenv("KS_DEBUG_ONE_CURSOR")) ? JN_SEGS : 1;
+                if (ix->fp_layout && getenv("KS_DEBUG_JOIN_SEGS") && n_buckets >= JN_SEGS) n_segs = JN_SEGS; // (tests: small inputs through the segmented path)
+            }
+            seg_cap = n_segs == 1 ? cap : cap / n_segs + cap / n_segs / 8 + 4096;
+            if (getenv("KS_DEBUG_JOIN_SEG_CAP")) seg_cap = strtoull(getenv("KS_DEBUG_JOIN_SEG_CAP"), nullptr, 10); // (tests: the retry)
             for (int attempt = 0; attempt < 2; attempt++) {
-                SE_CHECK(ks_alloc(ctx, &pk0, (size_t)cap));
-                if (!packed) SE_CHECK(ks_alloc(ctx, &pv0, (size_t)cap));
-                if (attempt > 0) SE_HIP(hipMemsetAsync(cursor, 0, sizeof(u64), ctx->stream)); // (attempt 0: cleared with the flag word above)
+                SE_CHECK(ks_alloc(ctx, &pk0, (size_t)(seg_cap * n_segs)));
+                if (!packed) SE_CHECK(ks_alloc(ctx, &pv0, (size_t)(seg_cap * n_segs)));
+                if (attempt > 0) SE_HIP(hipMemsetAsync(cursor, 0, (size_t)JN_SEGS * JN_CUR_STRIDE * sizeof(u64), ctx->stream)); // (attempt 0: cleared with the flag word above)
                 ks_timer_begin(ctx, "join_buckets");
-                hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
-                                   (const u32 *)qv, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds,
-                                   q_lo, q_hi, dir_t, pk0, pv0, cap, cursor, tbits, abits);
+                if (ix->fp_layout)
+                    hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
+                                       (const u32 *)qv, (const u32 *)ix->d_fp, (const ks_post *)ix->d_post, (const ks_bmeta *)ix->d_bmeta, q_lo,
+                                       q_hi, dir_t, pk0, pv0, seg_cap, cursor, n_segs - 1, tbits, abits, ix->fp_shift);
+                else
+                    hipLaunchKernelGGL(k_join_buckets_keys, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
+                                       (const u32 *)qv, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds,
+                                       q_lo, q_hi, dir_t, pk0, pv0, seg_cap, cursor, tbits, abits);
                 ks_timer_end(ctx);
                 SE_HIP(hipGetLastError());
-                SE_HIP(hipMemcpyAsync(ctx->h_pin, cursor, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+                // the segment counts and the flag words: one strided copy
+                SE_HIP(hipMemcpy2DAsync(ctx->h_pin, sizeof(u64), cursor, (size_t)JN_CUR_STRIDE * sizeof(u64), sizeof(u64), JN_SEGS, hipMemcpyDeviceToHost, ctx->stream));
+                SE_HIP(hipMemcpyAsync(ctx->h_pin + JN_SEGS, flagw, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
                 SE_HIP(hipStreamSynchronize(ctx->stream));
-                n_pairs = ctx->h_pin[0];
-                overflowed = way == 0 && ctx->h_pin[1] != 0;
+                n_pairs = 0;
+                u64 seg_max = 0;
+                for (u32 s_ = 0; s_ < n_segs; s_++) {
+                    seg_count[s_] = ctx->h_pin[s_];
+                    n_pairs += seg_count[s_];
+                    if (seg_count[s_] > seg_max) seg_max = seg_count[s_];
+                }
+                overflowed = way == 0 && ctx->h_pin[JN_SEGS + 1] != 0;
                 if (!overflowed && n_pairs >= KS_PAIR_LIMIT) { // saturated alphabets: the caller searches the queries in slices
                     *split_pairs = n_pairs;
                     split = true;
                     goto done;
                 }
-                if (overflowed || n_pairs <= cap) break;
+                if (overflowed || seg_max <= seg_cap) break;
                 if (attempt == 1) {
-                    st = ks_fail(ctx, KS_ERR_CAPACITY, "search produced %llu matched posting pairs (cap %llu)",
-                                 (unsigned long long)n_pairs, (unsigned long long)cap);
+                    st = ks_fail(ctx, KS_ERR_CAPACITY, "search produced %llu matched posting pairs (segment cap %llu)",
+                                 (unsigned long long)n_pairs, (unsigned long long)seg_cap);
                     goto done;
                 }
                 ks_pool_free(ctx, pk0); ks_pool_free(ctx, pv0); pk0 = nullptr; pv0 = nullptr;
-                cap = n_pairs;
+                seg_cap = seg_max; // (same postings, same buckets, same segments: the repeat fits exactly)
+                ctx->join_retries++;
             }
             ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1); ks_pool_free(ctx, bcur);
             qk0 = qk1 = nullptr; qv0 = qv1 = nullptr; bcur = nullptr;
@@ -688,6 +1107,21 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         // sort matches by (qid, tid) on the live id bits only
         SE_CHECK(ks_alloc(ctx, &pk1, (size_t)n_pairs));
         if (!packed) SE_CHECK(ks_alloc(ctx, &pv1, (size_t)n_pairs));
+        if (n_segs > 1) { // the segments -> one dense list (then the roles of the two buffers swap: the segmented one is the scratch)
+            jn_seg_table tab;
+            u64 acc = 0;
+            for (u32 s_ = 0; s_ < n_segs; s_++) { tab.prefix[s_] = acc; acc += seg_count[s_]; }
+            tab.prefix[n_segs] = acc;
+            u64 seg_max = 0;
+            for (u32 s_ = 0; s_ < n_segs; s_++) if (seg_count[s_] > seg_max) seg_max = seg_count[s_];
+            ks_timer_begin(ctx, "pairs_compact");
+            hipLaunchKernelGGL(k_pairs_compact, dim3((u32)((seg_max + 2047) / 2048), n_segs), dim3(256), 0, ctx->stream, (const u64 *)pk0,
+                               (const u32 *)pv0, seg_cap, tab, pk1, pv1);
+            ks_timer_end(ctx);
+            SE_HIP(hipGetLastError());
+            u64 *tk = pk0; pk0 = pk1; pk1 = tk;
+            u32 *tv = pv0; pv0 = pv1; pv1 = tv;
+        }
         u64 *pk = nullptr;
         u32 *pv = nullptr;
         {

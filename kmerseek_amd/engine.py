@@ -151,6 +151,12 @@ class Context:
         self._check(self._L.ks_ctx_sketch_stats(self._h, C.byref(v)))
         return {"ticket_fallbacks": int(v[0]), "uses_ticket": int(v[1]), "compact_fallbacks": int(v[2]), "cap_fallbacks": int(v[3])}
 
+    def search_stats(self) -> Dict[str, int]:
+        """Repeats ks_search needed so far on this context (see ks_ctx_search_stats)."""
+        v = (C.c_uint64 * 2)()
+        self._check(self._L.ks_ctx_search_stats(self._h, C.byref(v)))
+        return {"join_retries": int(v[0])}
+
     # ---- sketch ----
     def sketch_batch(self, residues: np.ndarray, offsets: np.ndarray, ksize: int, scaled: int, moltype: str,
                      seed: int = SEED) -> "Sketches":

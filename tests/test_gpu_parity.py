@@ -669,3 +669,47 @@ def test_compacting_tiles_and_bounded_outputs_fall_back_exactly(ctx):
     s0 = ctx.sketch_stats()
     assert_sketch_parity(ctx, res3, offs3, 16, 5, "dayhoff")
     assert ctx.sketch_stats() == s0
+
+
+@pytest.mark.parametrize("k,scaled,mol,nt,nq", [(10, 1, "protein", 6000, 4000), (5, 1, "hp", 150, 120), (16, 5, "dayhoff", 30000, 20000)])
+def test_join_fingerprints_segments_and_retry_are_exact(ctx, monkeypatch, k, scaled, mol, nt, nq):
+    """The join streams 32-bit fingerprints of the index hashes and confirms candidates on the full 64-bit key; its match list
+    is cut into segments with one cursor each, copied dense afterwards, and repeated with exact segment sizes when a segment
+    overflows.  Every variant — fingerprints coarsened until most candidates are false, segmented / one-cursor list, a
+    segment capacity that forces the repeat — must give the oracle's rows."""
+    t_res, t_off = synth.proteome(nt, stream=300 + k)
+    q_res, q_off = synth.queries(nq, t_res, t_off, stream=301 + k)
+    want_t = oracle.sketch_batch(t_res, t_off, k, scaled, mol, n_threads=8)
+    want_q = oracle.sketch_batch(q_res, q_off, k, scaled, mol, n_threads=8)
+    want = oracle.manysearch(want_q[0], want_q[1], want_t[0], want_t[1], want_t[2], n_threads=8)
+    T = ctx.sketch_batch(t_res, t_off, k, scaled, mol)
+    Q = ctx.sketch_batch(q_res, q_off, k, scaled, mol)
+
+    def check(label):
+        ix = ctx.index_build(T)   # (the fingerprint width is a property of the index)
+        hits = ctx.search(ix, Q)
+        got = hits.to_host()
+        assert hits.n_pair_instances == int(want[2].sum()), label
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), label
+        hits.free(); ix.free()
+
+    check("default (columns)")
+    monkeypatch.setenv("KS_DEBUG_JOIN_FP", "1")   # the layout of big indexes, on a small one
+    check("fingerprints")
+    for coarsen in ("8", "20", "40"):
+        monkeypatch.setenv("KS_DEBUG_FP_COARSEN", coarsen)
+        check("coarse fingerprints +" + coarsen)
+    monkeypatch.setenv("KS_DEBUG_JOIN_SEGS", "1")
+    check("coarse + segments")
+    monkeypatch.delenv("KS_DEBUG_FP_COARSEN")
+    check("segments")
+    before = ctx.search_stats()["join_retries"]
+    monkeypatch.setenv("KS_DEBUG_JOIN_SEG_CAP", "16")
+    check("segments, capacity 16 -> repeat")
+    assert ctx.search_stats()["join_retries"] > before
+    monkeypatch.delenv("KS_DEBUG_JOIN_SEGS")
+    monkeypatch.setenv("KS_DEBUG_ONE_CURSOR", "1")
+    check("one cursor, capacity 16 -> repeat")
+    monkeypatch.delenv("KS_DEBUG_JOIN_SEG_CAP")
+    check("one cursor")
