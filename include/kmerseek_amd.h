@@ -99,7 +99,8 @@ int ks_ctx_pool_stats(const ks_ctx *ctx, uint64_t *n_blocks, uint64_t *bytes_hel
  * out[3] = batches repeated with window-count sized outputs because they kept more hashes than the expected 1/scaled. */
 int ks_ctx_sketch_stats(const ks_ctx *ctx, uint64_t out[4]);
 /* The same for ks_search: out[0] = searches that ran their join twice because the match list outgrew its first guess
- * (the list is sized from the previous search of the context), out[1] = reserved (0). */
+ * (the list is sized from the previous search of the context), out[1] = searches whose row pass was repeated with
+ * ticket-ordered tiles because a look-back gave up (the context then uses tickets for good). */
 int ks_ctx_search_stats(const ks_ctx *ctx, uint64_t out[2]);
 
 /* Plain device buffers for callers that have no HIP binding of their own (the *_device entry points take raw

@@ -65,6 +65,7 @@ struct ks_ctx {
     // how often a sketch batch had to be repeated: look-back gave up (-> ticket ids from then on), a compacting tile
     // overflowed its LDS lists (-> plain tiles for that batch), bounded outputs too small (-> window-count sized)
     u64 sketch_ticket_fallbacks = 0, sketch_compact_fallbacks = 0, sketch_cap_fallbacks = 0;
+    bool rows_use_ticket = false; u64 rows_ticket_fallbacks = 0; // k_pair_rows_fused: dispatch-order tile ids until a look-back gives up
     u64 join_retries = 0; // searches whose match list outgrew a segment and ran the join twice
     // single-launch scans (ks_prims.hip): status ring + ticket counter in device memory, never reset: every entry is
     // tagged with the global tile number that wrote it

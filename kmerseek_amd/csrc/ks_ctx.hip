@@ -167,7 +167,7 @@ extern "C" int ks_ctx_sketch_stats(const ks_ctx *ctx, uint64_t out[4]) {
 
 extern "C" int ks_ctx_search_stats(const ks_ctx *ctx, uint64_t out[2]) {
     if (!ctx || !out) return KS_ERR_INVALID_ARG;
-    out[0] = ctx->join_retries; out[1] = 0;
+    out[0] = ctx->join_retries; out[1] = ctx->rows_ticket_fallbacks;
     return KS_OK;
 }
 

@@ -21,6 +21,7 @@
 #define MS_IPT 16
 #define MS_TILE (MS_THREADS * MS_IPT) // 8192 records per tile of a partition pass
 #define MS_WAVES (MS_THREADS / 64)
+#define MS_SUB 8u // level-1 sub-histograms
 
 // Digit of a record at a level: NB = 256 -> 8 bits at `shift`; NB = 512 -> the 16 bits at `shift` RELATIVE to the tile's
 // base (the level-1 digit of the tile's first record << 8): a tile of the level-1 output lies inside one level-1 region or
@@ -39,10 +40,13 @@ KS_DEV u32 ms_base(const u64 *keys, u64 tile_base, int shift, u32 mask, int bits
 }
 
 // hist[bin] += records of this tile per bin
+// (`sub_stride`: level 1 keeps MS_SUB histograms, tile t counting in number t mod MS_SUB — atomics on ONE address are served
+// one at a time, ~12 ns each, and a level-1 bin would take one from every tile; 0 = one histogram)
 template <int NB>
-__global__ __launch_bounds__(MS_THREADS) void k_msd_hist(const u64 *keys, u64 n, int shift, u32 *hist, u32 mask, int bits2) {
+__global__ __launch_bounds__(MS_THREADS) void k_msd_hist(const u64 *keys, u64 n, int shift, u32 *hist, u32 mask, int bits2, u32 sub_stride) {
     __shared__ u32 bins[NB];
     const u32 tid = threadIdx.x;
+    hist += (blockIdx.x & (MS_SUB - 1u)) * sub_stride;
     for (u32 i = tid; i < NB; i += MS_THREADS) bins[i] = 0;
     const u64 tile_base = (u64)blockIdx.x * MS_TILE;
     const u32 nvalid = (n - tile_base) < MS_TILE ? (u32)(n - tile_base) : MS_TILE;
@@ -62,21 +66,26 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_hist(const u64 *keys, u64 n,
         if (bins[i]) atomicAdd(&hist[base + i], bins[i]);
 }
 
-// 256 counts -> exclusive offsets in place (one workgroup)
-__global__ __launch_bounds__(256) void k_msd_scan256(u32 *hist, u32 n) {
+// 256 counts (in n_sub histograms, sub-major) -> exclusive offsets in place (one workgroup): the cursor of (sub, bin) starts
+// where the records of the lower subs of that bin end
+__global__ __launch_bounds__(256) void k_msd_scan256(u32 *hist, u32 n_sub) {
     __shared__ u32 smem[256 / 64 + 1];
-    u32 total;
-    const u32 v = hist[threadIdx.x];
-    const u32 ex = ks_block_excl_scan(v, smem, &total);
-    hist[threadIdx.x] = ex;
-    (void)n;
+    u32 total, v = 0;
+    for (u32 s = 0; s < n_sub; s++) v += hist[s * 256u + threadIdx.x];
+    u32 run = ks_block_excl_scan(v, smem, &total);
+    for (u32 s = 0; s < n_sub; s++) {
+        const u32 c = hist[s * 256u + threadIdx.x];
+        hist[s * 256u + threadIdx.x] = run;
+        run += c;
+    }
 }
 
 // One partition pass: record -> bin cursor (exact sizes).  Ranks inside (tile, bin) are LDS atomic returns, one global
 // atomic per (tile, non-empty bin) reserves the slice, records leave through LDS in bin order so that every bin is
 // written as one contiguous run.
 template <int NB>
-__global__ __launch_bounds__(MS_THREADS, 2) void k_msd_scatter(const u64 *kin, u64 *kout, u64 n, int shift, u32 *cur, u32 mask, int bits2) {
+__global__ __launch_bounds__(MS_THREADS, 2) void k_msd_scatter(const u64 *kin, u64 *kout, u64 n, int shift, u32 *cur, u32 mask, int bits2,
+                                                               u32 sub_stride) {
     __shared__ u32 cnt[NB];
     __shared__ u32 dstart[NB];
     __shared__ u32 gbase[NB];
@@ -86,6 +95,7 @@ __global__ __launch_bounds__(MS_THREADS, 2) void k_msd_scatter(const u64 *kin, u
     const u32 bid = ks_xcd_block(); // neighbouring tiles (whose runs meet in the same cache lines) share one L2
     const u64 tile_base = (u64)bid * MS_TILE;
     const u32 nvalid = (n - tile_base) < MS_TILE ? (u32)(n - tile_base) : MS_TILE;
+    cur += (bid & (MS_SUB - 1u)) * sub_stride; // (the cursors of this tile's sub-histogram, see k_msd_hist)
     for (u32 i = tid; i < NB; i += MS_THREADS) cnt[i] = 0;
     const u32 base = ms_base<NB>(kin, tile_base, shift, mask, bits2);
     u64 key[MS_IPT];
@@ -400,20 +410,23 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
     // offsets double as the scatter's cursors: once spent, cursor[b] is the END of bucket b, which is all the local sort needs
     // (no copy of the offsets is kept).
     u32 *blk = nullptr, *off2 = nullptr;
-    int st = ks_alloc(ctx, &blk, 256 + 1 + 65536 + 1);
+    // (level 1 followed by level 2: MS_SUB histograms; level 1 alone — short lists — one, whose spent cursors are the ends)
+    const u32 n_sub = bits2 > 0 ? MS_SUB : 1u, sub_stride = bits2 > 0 ? 256u : 0u;
+    int st = ks_alloc(ctx, &blk, 256 * MS_SUB + 1 + 65536 + 1);
     if (st == KS_OK) st = ks_alloc(ctx, &off2, 65536 + 1);
-    u32 *off1 = blk, *big = blk ? blk + 256 : nullptr;
+    u32 *off1 = blk, *big = blk ? blk + 256 * MS_SUB : nullptr;
     u64 *sorted_in = ka; // where the partitioned list ends up
     if (st == KS_OK) {
-        (void)hipMemsetAsync(blk, 0, 257 * sizeof(u32), ctx->stream);
+        (void)hipMemsetAsync(blk, 0, (256 * MS_SUB + 1) * sizeof(u32), ctx->stream);
         ks_timer_begin(ctx, "msd_hist");
-        hipLaunchKernelGGL((k_msd_hist<256>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, n, shift1, off1, 255u, 0);
+        hipLaunchKernelGGL((k_msd_hist<256>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, n, shift1, off1, 255u, 0, sub_stride);
         ks_timer_end(ctx);
         ks_timer_begin(ctx, "msd_scan");
-        hipLaunchKernelGGL(k_msd_scan256, dim3(1), dim3(256), 0, ctx->stream, off1, (u32)n);
+        hipLaunchKernelGGL(k_msd_scan256, dim3(1), dim3(256), 0, ctx->stream, off1, n_sub);
         ks_timer_end(ctx);
         ks_timer_begin(ctx, "msd_scatter");
-        hipLaunchKernelGGL((k_msd_scatter<256>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, kb, n, shift1, off1, 255u, 0);
+        hipLaunchKernelGGL((k_msd_scatter<256>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, kb, n, shift1, off1, 255u, 0,
+                           sub_stride);
         ks_timer_end(ctx);
         sorted_in = kb;
     }
@@ -421,12 +434,12 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
     if (st == KS_OK && bits2 > 0) {
         (void)hipMemsetAsync(off2, 0, ((size_t)n_buckets + 1) * sizeof(u32), ctx->stream);
         ks_timer_begin(ctx, "msd_hist");
-        hipLaunchKernelGGL((k_msd_hist<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, n, shift2, off2, mask2, bits2);
+        hipLaunchKernelGGL((k_msd_hist<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, n, shift2, off2, mask2, bits2, 0u);
         ks_timer_end(ctx);
         st = ks_scan_u32_inplace(ctx, off2, n_buckets, nullptr);
         if (st == KS_OK) {
             ks_timer_begin(ctx, "msd_scatter");
-            hipLaunchKernelGGL((k_msd_scatter<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, ka, n, shift2, off2, mask2, bits2);
+            hipLaunchKernelGGL((k_msd_scatter<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, ka, n, shift2, off2, mask2, bits2, 0u);
             ks_timer_end(ctx);
             sorted_in = ka;
             off = off2;

@@ -821,14 +821,21 @@ __global__ __launch_bounds__(256) void k_pair_reduce(const u64 *keys, const u32 
 
 __global__ __launch_bounds__(PF_THREADS) void k_pair_rows_fused(const u64 *keys, u64 n, u32 *qid, u32 *tid, u32 *isect, unsigned long long *nw,
                                                                 int tbits, int abits, u32 rows_cap, unsigned long long *status,
-                                                                u32 *ticket /* [0] tile ids, [1] a look-back gave up */, u32 *n_rows_out) {
+                                                                u32 *ticket /* [0] tile ids, [1] a look-back gave up */, u32 *n_rows_out,
+                                                                int use_ticket) {
     __shared__ u32 tile_s;
     __shared__ u32 wcount[PF_IPT][PF_WAVES]; // heads per (round, wave), then exclusive offsets inside the tile
     __shared__ unsigned long long base_s;
     const u32 tid_ = threadIdx.x, lane = tid_ & 63, wave = tid_ >> 6;
-    if (tid_ == 0) tile_s = atomicAdd(&ticket[0], 1u);
-    __syncthreads();
-    const u32 tile = tile_s;
+    // Tile ids in dispatch order (blockIdx.x): workgroups start in that order on this hardware, so a tile's predecessors are
+    // running or done when it looks back.  That is not a documented guarantee: the look-back spins for a bounded time, and a
+    // launch in which one gave up is repeated with ids from an atomic ticket (order of arrival; ~12 ns per ticket on one
+    // address — 10^4 tiles are 0.1 ms of queueing, most of this kernel's former run time).
+    if (use_ticket) { // uniform
+        if (tid_ == 0) tile_s = atomicAdd(&ticket[0], 1u);
+        __syncthreads();
+    }
+    const u32 tile = use_ticket ? tile_s : blockIdx.x;
     const u64 b0 = (u64)tile * PF_TILE;
     u64 key[PF_IPT];
     u32 headbits = 0;
@@ -1157,7 +1164,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         u64 rows_cap = n_pairs;
         if (ctx->rows_hint && ctx->rows_hint < rows_cap && !getenv("KS_DEBUG_NO_ROWS_HINT")) rows_cap = ctx->rows_hint;
         u32 n_rows = 0;
-        for (int attempt = 0; attempt < 2; attempt++) {
+        for (int attempt = 0; attempt < 3; attempt++) { // (repeats: more rows than the guess; a look-back that gave up)
             SE_CHECK(ks_alloc(ctx, &H->d_qid, (size_t)rows_cap)); SE_CHECK(ks_alloc(ctx, &H->d_tid, (size_t)rows_cap));
             SE_CHECK(ks_alloc(ctx, &H->d_isect, (size_t)rows_cap)); SE_CHECK(ks_alloc(ctx, &H->d_nw, (size_t)rows_cap));
             SE_HIP(hipMemsetAsync(H->d_isect, 0, (size_t)rows_cap * sizeof(u32), ctx->stream));
@@ -1166,7 +1173,8 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 SE_HIP(hipMemsetAsync(pf_status, 0, ((size_t)pf_tiles + 1) * sizeof(u64), ctx->stream));
                 ks_timer_begin(ctx, "pair_rows");
                 hipLaunchKernelGGL(k_pair_rows_fused, dim3(pf_tiles), dim3(PF_THREADS), 0, ctx->stream, (const u64 *)pk, n_pairs, H->d_qid, H->d_tid,
-                                   H->d_isect, (unsigned long long *)H->d_nw, tbits, abits, (u32)rows_cap, pf_status, pf_ticket, d_nrows);
+                                   H->d_isect, (unsigned long long *)H->d_nw, tbits, abits, (u32)rows_cap, pf_status, pf_ticket, d_nrows,
+                                   (ctx->rows_use_ticket || getenv("KS_DEBUG_ROWS_TICKET")) ? 1 : 0);
                 ks_timer_end(ctx);
                 SE_HIP(hipMemcpyAsync(ctx->h_pin + 1, pf_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
             } else {
@@ -1180,13 +1188,21 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             SE_CHECK(ks_scan_status_fetch(ctx));
             SE_HIP(hipStreamSynchronize(ctx->stream));
             SE_CHECK(ks_scan_status_check(ctx));
-            if (fused && ((u32 *)(ctx->h_pin + 1))[1] != 0) { st = ks_fail(ctx, KS_ERR_HIP, "search: row look-back gave up waiting for a predecessor tile"); goto done; }
-            n_rows = *(u32 *)ctx->h_pin;
-            if (n_rows <= rows_cap) break;
+            bool gave_up = fused && ((u32 *)(ctx->h_pin + 1))[1] != 0;
+            if (fused && getenv("KS_DEBUG_FORCE_ROWS_TICKET_RETRY") && !ctx->rows_use_ticket) gave_up = true; // (tests)
+            if (gave_up) {
+                if (ctx->rows_use_ticket || attempt == 2) { st = ks_fail(ctx, KS_ERR_HIP, "search: row look-back gave up waiting for a predecessor tile"); goto done; }
+                ctx->rows_use_ticket = true; // dispatch order did not hold here: tickets from now on
+                ctx->rows_ticket_fallbacks++;
+            } else {
+                n_rows = *(u32 *)ctx->h_pin;
+                if (n_rows <= rows_cap) break;
+                rows_cap = n_rows;
+            }
             ks_pool_free(ctx, H->d_qid); ks_pool_free(ctx, H->d_tid); ks_pool_free(ctx, H->d_isect); ks_pool_free(ctx, H->d_nw);
             H->d_qid = H->d_tid = H->d_isect = nullptr; H->d_nw = nullptr;
-            rows_cap = n_rows;
         }
+        if (!H->d_qid) { st = ks_fail(ctx, KS_ERR_HIP, "search: the row pass did not settle"); goto done; }
         H->n_hits = n_rows;
         {
             const u64 want = (u64)n_rows + n_rows / 4 + 4096;

@@ -155,7 +155,7 @@ class Context:
         """Repeats ks_search needed so far on this context (see ks_ctx_search_stats)."""
         v = (C.c_uint64 * 2)()
         self._check(self._L.ks_ctx_search_stats(self._h, C.byref(v)))
-        return {"join_retries": int(v[0])}
+        return {"join_retries": int(v[0]), "rows_ticket_fallbacks": int(v[1])}
 
     # ---- sketch ----
     def sketch_batch(self, residues: np.ndarray, offsets: np.ndarray, ksize: int, scaled: int, moltype: str,

@@ -713,3 +713,27 @@ def test_join_fingerprints_segments_and_retry_are_exact(ctx, monkeypatch, k, sca
     check("one cursor, capacity 16 -> repeat")
     monkeypatch.delenv("KS_DEBUG_JOIN_SEG_CAP")
     check("one cursor")
+
+
+def test_row_pass_repeats_with_ticket_ids_when_a_lookback_gives_up(monkeypatch):
+    """k_pair_rows_fused takes its tile ids from blockIdx.x (dispatch order); a launch whose look-back gave up is repeated with
+    ticket-ordered tiles and the context keeps tickets from then on.  Same rows either way."""
+    c = ks.Context(0)
+    try:
+        t_res, t_off = synth.proteome(3000, stream=410)
+        q_res, q_off = synth.queries(2500, t_res, t_off, stream=411)
+        T = c.sketch_batch(t_res, t_off, 7, 1, "hp")
+        Q = c.sketch_batch(q_res, q_off, 7, 1, "hp")
+        ix = c.index_build(T)
+        a = c.search(ix, Q).to_host()
+        assert len(a[0]) > 100_000 and c.search_stats()["rows_ticket_fallbacks"] == 0
+        monkeypatch.setenv("KS_DEBUG_FORCE_ROWS_TICKET_RETRY", "1")
+        b = c.search(ix, Q).to_host()
+        monkeypatch.delenv("KS_DEBUG_FORCE_ROWS_TICKET_RETRY")
+        assert c.search_stats()["rows_ticket_fallbacks"] == 1
+        d = c.search(ix, Q).to_host()   # tickets for good now
+        assert c.search_stats()["rows_ticket_fallbacks"] == 1
+        for x, y, z in zip(a, b, d):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+    finally:
+        c.close()
