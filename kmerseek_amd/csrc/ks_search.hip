@@ -972,10 +972,9 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         const u32 pfxK = ks_join_prefix_mul(pbits, ks_max_hash(ix->params.scaled));
         SE_CHECK(ks_alloc(ctx, &dir_q, (size_t)2 * n_buckets + 2));
         const u64 *dir_t = ix->d_dir; // built with the index
-        // cursor block: segment s of the pair list counts at word s * JN_CUR_STRIDE; after the last segment, [+1] = "a query
-        // bucket overflowed" (k_bucket_scatter)
-        SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, (size_t)(JN_SEGS + 1) * JN_CUR_STRIDE));
-        unsigned long long *const flagw = cursor + (size_t)JN_SEGS * JN_CUR_STRIDE;
+        // cursor block: segment s of the pair list counts at word s * JN_CUR_STRIDE; word 1 = "a query bucket overflowed"
+        // (k_bucket_scatter)
+        SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, (size_t)JN_SEGS * JN_CUR_STRIDE));
         const bool pre = q->part_keys && q->part_pbits == pbits && q->part_K == pfxK && pbits > 0;
         u64 cap = n_q < (1u << 20) ? (1u << 20) : n_q;
         if (ctx->pair_cap_hint > cap) cap = ctx->pair_cap_hint; // a workload that matched heavily last time will again
@@ -987,7 +986,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             u64 *qk = nullptr;
             u32 *qv = nullptr;
             const u64 *q_lo = nullptr, *q_hi = nullptr;
-            SE_HIP(hipMemsetAsync(cursor, 0, ((size_t)JN_SEGS * JN_CUR_STRIDE + 2) * sizeof(u64), ctx->stream));
+            SE_HIP(hipMemsetAsync(cursor, 0, (size_t)JN_SEGS * JN_CUR_STRIDE * sizeof(u64), ctx->stream));
             if (way == 0) {
                 const u64 per = n_q / n_buckets;
                 const u32 bcap = (u32)(per + per / 8 + 512);
@@ -996,7 +995,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 SE_CHECK(ks_alloc(ctx, &bcur, (size_t)n_buckets));
                 SE_HIP(hipMemsetAsync(bcur, 0, (size_t)n_buckets * sizeof(u32), ctx->stream));
                 ks_rs_segments seg{q->part_len, q->part_cap, q->part_regions << q->part_sub_shift, q->part_sub_shift};
-                SE_CHECK(ks_bucket_scatter_u32(ctx, q->part_keys, q->part_vals, &seg, 8, pfxK, qk0, qv0, bcur, bcap, flagw, n_buckets >> 8));
+                SE_CHECK(ks_bucket_scatter_u32(ctx, q->part_keys, q->part_vals, &seg, 8, pfxK, qk0, qv0, bcur, bcap, cursor, n_buckets >> 8));
                 ks_timer_begin(ctx, "bucket_dir");
                 hipLaunchKernelGGL(k_region_dir, dim3((n_buckets + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)bcur, (u64)bcap,
                                    n_buckets, dir_q, dir_q + n_buckets, n_buckets >> 8);
@@ -1053,7 +1052,8 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             for (int attempt = 0; attempt < 2; attempt++) {
                 SE_CHECK(ks_alloc(ctx, &pk0, (size_t)(seg_cap * n_segs)));
                 if (!packed) SE_CHECK(ks_alloc(ctx, &pv0, (size_t)(seg_cap * n_segs)));
-                if (attempt > 0) SE_HIP(hipMemsetAsync(cursor, 0, (size_t)JN_SEGS * JN_CUR_STRIDE * sizeof(u64), ctx->stream)); // (attempt 0: cleared with the flag word above)
+                if (attempt > 0) // (attempt 0: cleared with the flag word above; the flag word survives)
+                    SE_HIP(hipMemset2DAsync(cursor, (size_t)JN_CUR_STRIDE * sizeof(u64), 0, sizeof(u64), JN_SEGS, ctx->stream));
                 ks_timer_begin(ctx, "join_buckets");
                 if (ix->fp_layout)
                     hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
@@ -1065,18 +1065,21 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                                        q_lo, q_hi, dir_t, pk0, pv0, seg_cap, cursor, tbits, abits);
                 ks_timer_end(ctx);
                 SE_HIP(hipGetLastError());
-                // the segment counts and the flag words: one strided copy
-                SE_HIP(hipMemcpy2DAsync(ctx->h_pin, sizeof(u64), cursor, (size_t)JN_CUR_STRIDE * sizeof(u64), sizeof(u64), JN_SEGS, hipMemcpyDeviceToHost, ctx->stream));
-                SE_HIP(hipMemcpyAsync(ctx->h_pin + JN_SEGS, flagw, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+                // the segment counts (+ the flag word beside the first): one copy, strided when the list is segmented
+                if (n_segs == 1)
+                    SE_HIP(hipMemcpyAsync(ctx->h_pin, cursor, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+                else
+                    SE_HIP(hipMemcpy2DAsync(ctx->h_pin, 2 * sizeof(u64), cursor, (size_t)JN_CUR_STRIDE * sizeof(u64), 2 * sizeof(u64), JN_SEGS,
+                                            hipMemcpyDeviceToHost, ctx->stream));
                 SE_HIP(hipStreamSynchronize(ctx->stream));
                 n_pairs = 0;
                 u64 seg_max = 0;
                 for (u32 s_ = 0; s_ < n_segs; s_++) {
-                    seg_count[s_] = ctx->h_pin[s_];
+                    seg_count[s_] = ctx->h_pin[2 * s_];
                     n_pairs += seg_count[s_];
                     if (seg_count[s_] > seg_max) seg_max = seg_count[s_];
                 }
-                overflowed = way == 0 && ctx->h_pin[JN_SEGS + 1] != 0;
+                overflowed = way == 0 && ctx->h_pin[1] != 0;
                 if (!overflowed && n_pairs >= KS_PAIR_LIMIT) { // saturated alphabets: the caller searches the queries in slices
                     *split_pairs = n_pairs;
                     split = true;
