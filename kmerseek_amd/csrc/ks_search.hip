@@ -725,6 +725,195 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
     }
 }
 
+// ---- the join of big indexes when the buckets hold FEW query postings (a query shard of a strong-scaling run, a small
+// batch against a big index): the roles swap.  The bucket's queries — a few hundred — are put in fingerprint-slot order in a
+// 16-KB LDS table with a directory over it; the index fingerprints are not staged at all: every thread takes its share of
+// them straight into registers and probes the table.  Same candidates, same confirmation on the 16-byte postings, same
+// per-wave reservation as k_join_buckets — but 256 threads and a third of the LDS per bucket, so 8 workgroups per CU instead
+// of 3 work on the chain of memory latencies a sparse bucket is.
+#define JS_THREADS 256
+#define JS_QCAP 1024  // query postings per table build (more: the bucket is joined in slices)
+#define JS_QE (JS_QCAP / JS_THREADS)
+#define JS_IPT 20     // index fingerprints per thread and pass
+#define JS_G 4        // ... of which this many are in flight per group
+#define JS_DIR 1024   // directory slots over the table
+#define JS_WLIST 128  // candidates a wave lists per pass
+KS_DEV u32 js_slot(u32 f, u32 mul) { // slot of a fingerprint: the bucket's JN_DIR slot mapping, coarsened
+    const u32 j = __umulhi(f, mul) >> 1; // (JN_DIR / JS_DIR = 2)
+    return j < (u32)JS_DIR - 1u ? j : (u32)JS_DIR - 1u;
+}
+static_assert(JN_DIR == 2 * JS_DIR, "js_slot halves the JN_DIR slot");
+__global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_join_sparse(
+    const u64 *qkeys, const u32 *qids, const u32 *ifp, const ks_post *ipost, const ks_bmeta *bmeta, const u64 *q_lo, const u64 *q_hi,
+    const u64 *dir_t, u64 *pair_keys, u32 *pair_vals, u64 cap, unsigned long long *cursors, u32 seg_mask, int tbits, int abits,
+    int fp_shift) {
+    __shared__ u64 qh[JS_QCAP];                       // query hashes, in slot order
+    __shared__ u32 qf[JS_QCAP];                       // their fingerprints
+    __shared__ unsigned short qi[JS_QCAP];            // their place in the bucket's posting list
+    __shared__ u32 qdir[JS_DIR + 1];                  // counts, then first table entry of every slot
+    __shared__ u32 wlist[JS_THREADS / 64][JS_WLIST];  // per-wave candidate list: index posting (this pass) << 10 | table entry
+    __shared__ u32 wcount[JS_THREADS / 64];
+    __shared__ u32 scan_smem[JS_THREADS / 64 + 1];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u64 qs = q_lo[blockIdx.x], qe = q_hi[blockIdx.x];
+    const u64 ts = dir_t[blockIdx.x], te = dir_t[blockIdx.x + 1];
+    const ks_bmeta bm = bmeta[blockIdx.x];
+    if (qs == qe || ts == te) return;
+    const u32 seg = blockIdx.x & seg_mask;
+    unsigned long long *cursor = cursors + (size_t)seg * JN_CUR_STRIDE;
+    pair_keys += (u64)seg * cap;
+    if (pair_vals) pair_vals += (u64)seg * cap;
+    const u64 kbase = bm.base;
+    const u32 dirM = bm.slot_mul;
+    for (u64 q0 = qs; q0 < qe; q0 += JS_QCAP) { // slices of the bucket's queries (one, normally)
+        const u32 nq = (u32)((qe - q0) < (u64)JS_QCAP ? (qe - q0) : (u64)JS_QCAP);
+        const u64 *qkr = qkeys + q0;
+        const u32 *qir = qids + q0;
+        // ---- the table: counting sort of the slice by fingerprint slot
+        u64 h[JS_QE];
+#pragma unroll
+        for (int e = 0; e < JS_QE; e++) {
+            const u32 i = (u32)e * JS_THREADS + tid;
+            h[e] = i < nq ? qkr[i] : 0;
+        }
+        for (u32 i = tid; i <= (u32)JS_DIR; i += JS_THREADS) qdir[i] = 0;
+        __syncthreads();
+        u32 code[JS_QE]; // slot << 16 | arrival inside the slot; 0xffffffff = no query / below the bucket's first key
+#pragma unroll
+        for (int e = 0; e < JS_QE; e++) {
+            const u32 i = (u32)e * JS_THREADS + tid;
+            code[e] = 0xffffffffu;
+            if (i < nq && h[e] >= kbase) {
+                const u32 sl = js_slot(jn_fingerprint(h[e], kbase, fp_shift), dirM);
+                code[e] = (sl << 16) | atomicAdd(&qdir[sl], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            u32 c[JS_DIR / JS_THREADS], sum = 0;
+#pragma unroll
+            for (int j = 0; j < JS_DIR / JS_THREADS; j++) { c[j] = qdir[tid * (JS_DIR / JS_THREADS) + j]; sum += c[j]; }
+            u32 total;
+            u32 ex = ks_block_excl_scan(sum, scan_smem, &total);
+#pragma unroll
+            for (int j = 0; j < JS_DIR / JS_THREADS; j++) { qdir[tid * (JS_DIR / JS_THREADS) + j] = ex; ex += c[j]; }
+            if (tid == JS_THREADS - 1) qdir[JS_DIR] = total;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < JS_QE; e++)
+            if (code[e] != 0xffffffffu) {
+                const u32 pos = qdir[code[e] >> 16] + (code[e] & 0xffffu);
+                qh[pos] = h[e];
+                qf[pos] = jn_fingerprint(h[e], kbase, fp_shift);
+                qi[pos] = (unsigned short)((u32)e * JS_THREADS + tid);
+            }
+        __syncthreads();
+        // ---- the index fingerprints of the bucket stream past the table, JS_THREADS * JS_IPT per pass
+        for (u64 c0 = ts; c0 < te; c0 += (u64)JS_THREADS * JS_IPT) {
+            const u32 n = (u32)((te - c0) < (u64)JS_THREADS * JS_IPT ? (te - c0) : (u64)JS_THREADS * JS_IPT);
+            const u32 *fpc = ifp + c0;
+            const ks_post *postc = ipost + c0;
+            if (lane == 0) wcount[wave] = 0;
+            __builtin_amdgcn_wave_barrier();
+            // groups of JS_G fingerprints per thread, the next group's loads in flight while this one probes the table
+            u32 fa[JS_G], fb[JS_G];
+#pragma unroll
+            for (int j = 0; j < JS_G; j++) {
+                const u32 i = (u32)j * JS_THREADS + tid;
+                fa[j] = i < n ? fpc[i] : 0;
+            }
+#pragma unroll 1
+            for (u32 g = 0; g < (u32)(JS_IPT / JS_G); g++) {
+                const u32 i0 = g * (u32)(JS_G * JS_THREADS);
+                if (i0 >= n) break; // (uniform)
+#pragma unroll
+                for (int j = 0; j < JS_G; j++) {
+                    const u32 i = i0 + (u32)(JS_G + j) * JS_THREADS + tid;
+                    fb[j] = (g + 1 < (u32)(JS_IPT / JS_G) && i < n) ? fpc[i] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < JS_G; j++) {
+                    const u32 i = i0 + (u32)j * JS_THREADS + tid;
+                    if (i < n) {
+                        const u32 sl = js_slot(fa[j], dirM);
+                        for (u32 r = qdir[sl]; r < qdir[sl + 1]; r++)
+                            if (qf[r] == fa[j]) {
+                                const u32 p = atomicAdd(&wcount[wave], 1u);
+                                if (p < (u32)JS_WLIST) wlist[wave][p] = (i << 10) | r;
+                            }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < JS_G; j++) fa[j] = fb[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const u32 wtotal = wcount[wave]; // candidates of this wave (uniform)
+            if (wtotal == 0) continue;
+            if (wtotal <= (u32)JS_WLIST) {
+                // lane k confirms and emits candidate k
+                u64 rk[JS_WLIST / 64];
+                u32 rv[JS_WLIST / 64], okm = 0, conf = 0;
+#pragma unroll
+                for (int it = 0; it < JS_WLIST / 64; it++) {
+                    rk[it] = 0; rv[it] = 0;
+                    const u32 k = (u32)it * 64u + lane;
+                    if (k < wtotal) {
+                        const u32 en = wlist[wave][k], r = en & 1023u;
+                        const ks_post pt = postc[en >> 10];
+                        const u32 q = qir[qi[r]];
+                        if (pt.key == qh[r]) {
+                            const u64 ids = ((u64)q << tbits) | pt.tid;
+                            rk[it] = pair_vals ? ids : ((ids << abits) | pt.abund);
+                            rv[it] = pt.abund;
+                            okm |= 1u << it;
+                            conf++;
+                        }
+                    }
+                }
+                const u32 cincl = ks_wave_incl_scan(conf);
+                const u32 total = __shfl(cincl, 63, 64);
+                if (total) { // uniform per wave
+                    unsigned long long wb = 0;
+                    if (lane == 0) wb = atomicAdd(cursor, (unsigned long long)total);
+                    wb = ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(wb >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)wb);
+                    u64 slot = wb + (cincl - conf);
+#pragma unroll
+                    for (int it = 0; it < JS_WLIST / 64; it++)
+                        if ((okm >> it) & 1u) {
+                            if (slot < cap) {
+                                pair_keys[slot] = rk[it];
+                                if (pair_vals) pair_vals[slot] = rv[it];
+                            }
+                            slot++;
+                        }
+                }
+            } else {
+                // more candidates than the list holds (a hash shared by many queries and targets): every lane confirms and
+                // emits its own, one reservation per pair — slow and exact
+#pragma unroll 1
+                for (u32 i = tid; i < n; i += JS_THREADS) {
+                    const u32 fj = fpc[i];
+                    const u32 sl = js_slot(fj, dirM);
+                    for (u32 r = qdir[sl]; r < qdir[sl + 1]; r++)
+                        if (qf[r] == fj) {
+                            const ks_post pt = postc[i];
+                            if (pt.key == qh[r]) {
+                                const u64 slot = atomicAdd(cursor, 1ULL);
+                                if (slot < cap) {
+                                    const u64 ids = ((u64)qir[qi[r]] << tbits) | pt.tid;
+                                    if (pair_vals) { pair_keys[slot] = ids; pair_vals[slot] = pt.abund; }
+                                    else pair_keys[slot] = (ids << abits) | pt.abund;
+                                }
+                            }
+                        }
+                }
+            }
+        }
+        __syncthreads(); // the table is rebuilt for the next slice
+    }
+}
+
 // the segments of the pair list (seg_cap records apart, prefix[s+1] - prefix[s] of them filled) -> one dense list
 struct jn_seg_table { u64 prefix[JN_SEGS + 1]; };
 __global__ __launch_bounds__(256) void k_pairs_compact(const u64 *src_k, const u32 *src_v, u64 seg_cap, jn_seg_table tab, u64 *dst_k, u32 *dst_v) {
@@ -1055,7 +1244,14 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 if (attempt > 0) // (attempt 0: cleared with the flag word above; the flag word survives)
                     SE_HIP(hipMemset2DAsync(cursor, (size_t)JN_CUR_STRIDE * sizeof(u64), 0, sizeof(u64), JN_SEGS, ctx->stream));
                 ks_timer_begin(ctx, "join_buckets");
-                if (ix->fp_layout)
+                // (few query postings per bucket: the table kernel; KS_DEBUG_JOIN_SPARSE = 0 / 1 forces the choice in the tests)
+                const bool sparse = ix->fp_layout && (getenv("KS_DEBUG_JOIN_SPARSE") ? atoi(getenv("KS_DEBUG_JOIN_SPARSE")) != 0
+                                                                                     : n_q / n_buckets <= (u64)JS_QCAP * 3 / 4);
+                if (sparse)
+                    hipLaunchKernelGGL(k_join_sparse, dim3(n_buckets), dim3(JS_THREADS), 0, ctx->stream, (const u64 *)qk,
+                                       (const u32 *)qv, (const u32 *)ix->d_fp, (const ks_post *)ix->d_post, (const ks_bmeta *)ix->d_bmeta, q_lo,
+                                       q_hi, dir_t, pk0, pv0, seg_cap, cursor, n_segs - 1, tbits, abits, ix->fp_shift);
+                else if (ix->fp_layout)
                     hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
                                        (const u32 *)qv, (const u32 *)ix->d_fp, (const ks_post *)ix->d_post, (const ks_bmeta *)ix->d_bmeta, q_lo,
                                        q_hi, dir_t, pk0, pv0, seg_cap, cursor, n_segs - 1, tbits, abits, ix->fp_shift);

@@ -696,7 +696,17 @@ def test_join_fingerprints_segments_and_retry_are_exact(ctx, monkeypatch, k, sca
 
     check("default (columns)")
     monkeypatch.setenv("KS_DEBUG_JOIN_FP", "1")   # the layout of big indexes, on a small one
-    check("fingerprints")
+    monkeypatch.setenv("KS_DEBUG_JOIN_SPARSE", "0")
+    check("fingerprints, staged index")
+    monkeypatch.setenv("KS_DEBUG_JOIN_SPARSE", "1")   # the kernel of sparse buckets (query table, streamed index)
+    check("fingerprints, query table")
+    monkeypatch.setenv("KS_DEBUG_FP_COARSEN", "20")
+    check("coarse fingerprints, query table")
+    monkeypatch.setenv("KS_DEBUG_JOIN_SEGS", "1")
+    check("coarse fingerprints, query table, segments")
+    monkeypatch.delenv("KS_DEBUG_JOIN_SEGS")
+    monkeypatch.delenv("KS_DEBUG_FP_COARSEN")
+    monkeypatch.setenv("KS_DEBUG_JOIN_SPARSE", "0")
     for coarsen in ("8", "20", "40"):
         monkeypatch.setenv("KS_DEBUG_FP_COARSEN", coarsen)
         check("coarse fingerprints +" + coarsen)
@@ -713,6 +723,8 @@ def test_join_fingerprints_segments_and_retry_are_exact(ctx, monkeypatch, k, sca
     check("one cursor, capacity 16 -> repeat")
     monkeypatch.delenv("KS_DEBUG_JOIN_SEG_CAP")
     check("one cursor")
+    monkeypatch.setenv("KS_DEBUG_JOIN_SPARSE", "1")
+    check("one cursor, query table")
 
 
 def test_row_pass_repeats_with_ticket_ids_when_a_lookback_gives_up(monkeypatch):
