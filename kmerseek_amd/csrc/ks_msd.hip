@@ -406,18 +406,19 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
         const u32 v = (u32)atoi(f);
         if (v >= 2 && v < ML_CAP) lds_cap = v;
     }
-    // off1 | big list share one block so that one memset clears the level-1 histogram and the list's counter.  The exclusive
-    // offsets double as the scatter's cursors: once spent, cursor[b] is the END of bucket b, which is all the local sort needs
-    // (no copy of the offsets is kept).
-    u32 *blk = nullptr, *off2 = nullptr;
+    // The exclusive offsets double as the scatter's cursors: once spent, cursor[b] is the END of bucket b, which is all the
+    // local sort needs (no copy of the offsets is kept).
+    // Layout of the one block: off1 (256 x MS_SUB) | off2 (n_buckets + 1, when there is a level 2) | big-list counter | big list
+    // — everything that starts at zero comes first, so ONE memset clears both histograms and the counter.
+    u32 *blk = nullptr;
     // (level 1 followed by level 2: MS_SUB histograms; level 1 alone — short lists — one, whose spent cursors are the ends)
     const u32 n_sub = bits2 > 0 ? MS_SUB : 1u, sub_stride = bits2 > 0 ? 256u : 0u;
-    int st = ks_alloc(ctx, &blk, 256 * MS_SUB + 1 + 65536 + 1);
-    if (st == KS_OK) st = ks_alloc(ctx, &off2, 65536 + 1);
-    u32 *off1 = blk, *big = blk ? blk + 256 * MS_SUB : nullptr;
+    const size_t off2_words = bits2 > 0 ? (size_t)n_buckets + 1 : 0, n_zero = 256 * MS_SUB + off2_words + 1;
+    int st = ks_alloc(ctx, &blk, n_zero + 65536 + 1);
+    u32 *off1 = blk, *off2 = blk ? blk + 256 * MS_SUB : nullptr, *big = blk ? blk + 256 * MS_SUB + off2_words : nullptr;
     u64 *sorted_in = ka; // where the partitioned list ends up
     if (st == KS_OK) {
-        (void)hipMemsetAsync(blk, 0, (256 * MS_SUB + 1) * sizeof(u32), ctx->stream);
+        (void)hipMemsetAsync(blk, 0, n_zero * sizeof(u32), ctx->stream);
         ks_timer_begin(ctx, "msd_hist");
         hipLaunchKernelGGL((k_msd_hist<256>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, n, shift1, off1, 255u, 0, sub_stride);
         ks_timer_end(ctx);
@@ -432,7 +433,6 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
     }
     const u32 *off = off1;
     if (st == KS_OK && bits2 > 0) {
-        (void)hipMemsetAsync(off2, 0, ((size_t)n_buckets + 1) * sizeof(u32), ctx->stream);
         ks_timer_begin(ctx, "msd_hist");
         hipLaunchKernelGGL((k_msd_hist<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, n, shift2, off2, mask2, bits2, 0u);
         ks_timer_end(ctx);
@@ -461,6 +461,6 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
         if (st == KS_OK && hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "msd sort launch failed");
         if (st == KS_OK) *done = 1;
     }
-    ks_pool_free(ctx, blk); ks_pool_free(ctx, off2);
+    ks_pool_free(ctx, blk);
     return st;
 }

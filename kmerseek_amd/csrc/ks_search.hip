@@ -1134,7 +1134,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
     H->ctx = ctx;
     const u64 n_q = q->n_hashes, n_t = ix->n_postings;
     u64 *qk0 = nullptr, *qk1 = nullptr, *pk0 = nullptr, *pk1 = nullptr, *row_start = nullptr, *dir_q = nullptr;
-    u32 *qv0 = nullptr, *qv1 = nullptr, *pv0 = nullptr, *pv1 = nullptr, *heads = nullptr, *d_nrows = nullptr, *bcur = nullptr;
+    u32 *qv0 = nullptr, *qv1 = nullptr, *pv0 = nullptr, *pv1 = nullptr, *heads = nullptr, *d_nrows = nullptr;
     unsigned long long *cursor = nullptr, *pf_status = nullptr;
     u32 *pf_ticket = nullptr;
     int st = KS_OK;
@@ -1163,7 +1163,9 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         const u64 *dir_t = ix->d_dir; // built with the index
         // cursor block: segment s of the pair list counts at word s * JN_CUR_STRIDE; word 1 = "a query bucket overflowed"
         // (k_bucket_scatter)
-        SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, (size_t)JN_SEGS * JN_CUR_STRIDE));
+        // (+ the join buckets' fill counts right behind it: one allocation, one memset)
+        SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, (size_t)JN_SEGS * JN_CUR_STRIDE + (n_buckets + 1) / 2));
+        u32 *const bcur = (u32 *)(cursor + (size_t)JN_SEGS * JN_CUR_STRIDE);
         const bool pre = q->part_keys && q->part_pbits == pbits && q->part_K == pfxK && pbits > 0;
         u64 cap = n_q < (1u << 20) ? (1u << 20) : n_q;
         if (ctx->pair_cap_hint > cap) cap = ctx->pair_cap_hint; // a workload that matched heavily last time will again
@@ -1175,14 +1177,12 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             u64 *qk = nullptr;
             u32 *qv = nullptr;
             const u64 *q_lo = nullptr, *q_hi = nullptr;
-            SE_HIP(hipMemsetAsync(cursor, 0, (size_t)JN_SEGS * JN_CUR_STRIDE * sizeof(u64), ctx->stream));
+            SE_HIP(hipMemsetAsync(cursor, 0, ((size_t)JN_SEGS * JN_CUR_STRIDE + (way == 0 ? (n_buckets + 1) / 2 : 0)) * sizeof(u64), ctx->stream));
             if (way == 0) {
                 const u64 per = n_q / n_buckets;
                 const u32 bcap = (u32)(per + per / 8 + 512);
                 SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_buckets * bcap));
                 SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_buckets * bcap));
-                SE_CHECK(ks_alloc(ctx, &bcur, (size_t)n_buckets));
-                SE_HIP(hipMemsetAsync(bcur, 0, (size_t)n_buckets * sizeof(u32), ctx->stream));
                 ks_rs_segments seg{q->part_len, q->part_cap, q->part_regions << q->part_sub_shift, q->part_sub_shift};
                 SE_CHECK(ks_bucket_scatter_u32(ctx, q->part_keys, q->part_vals, &seg, 8, pfxK, qk0, qv0, bcur, bcap, cursor, n_buckets >> 8));
                 ks_timer_begin(ctx, "bucket_dir");
@@ -1291,8 +1291,8 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 seg_cap = seg_max; // (same postings, same buckets, same segments: the repeat fits exactly)
                 ctx->join_retries++;
             }
-            ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1); ks_pool_free(ctx, bcur);
-            qk0 = qk1 = nullptr; qv0 = qv1 = nullptr; bcur = nullptr;
+            ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
+            qk0 = qk1 = nullptr; qv0 = qv1 = nullptr;
             if (!overflowed) {
                 H->partition_path = way == 0 ? 1 : (pre ? (pbits <= 8 ? 0 : 2) : 3);
                 break;
@@ -1344,13 +1344,16 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         // run-length reduce: one fused pass for packed records (k_pair_rows_fused); heads + scan + reduce when the
         // abundances travel apart (ids + abundance wider than 64 bits)
         const bool fused = packed && !getenv("KS_DEBUG_UNFUSED_ROWS");
-        SE_CHECK(ks_alloc(ctx, &d_nrows, 1));
         const u32 gp = (u32)((n_pairs + 255) / 256);
         const u32 pf_tiles = (u32)((n_pairs + PF_TILE - 1) / PF_TILE);
-        if (fused) { // status words and the ticket pair in one block: one memset
-            SE_CHECK(ks_alloc(ctx, (u64 **)&pf_status, (size_t)pf_tiles + 1));
+        u32 *nrows_dev = nullptr;
+        if (fused) { // status words, the ticket pair and the row count in one block: one memset, one copy back
+            SE_CHECK(ks_alloc(ctx, (u64 **)&pf_status, (size_t)pf_tiles + 2));
             pf_ticket = (u32 *)(pf_status + pf_tiles);
+            nrows_dev = pf_ticket + 2;
         } else {
+            SE_CHECK(ks_alloc(ctx, &d_nrows, 1));
+            nrows_dev = d_nrows;
             SE_CHECK(ks_alloc(ctx, &heads, (size_t)n_pairs));
             ks_timer_begin(ctx, "pair_heads");
             hipLaunchKernelGGL(k_pair_heads, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, n_pairs, heads, abits);
@@ -1369,13 +1372,13 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             SE_HIP(hipMemsetAsync(H->d_isect, 0, (size_t)rows_cap * sizeof(u32), ctx->stream));
             SE_HIP(hipMemsetAsync(H->d_nw, 0, (size_t)rows_cap * sizeof(u64), ctx->stream));
             if (fused) {
-                SE_HIP(hipMemsetAsync(pf_status, 0, ((size_t)pf_tiles + 1) * sizeof(u64), ctx->stream));
+                SE_HIP(hipMemsetAsync(pf_status, 0, ((size_t)pf_tiles + 2) * sizeof(u64), ctx->stream));
                 ks_timer_begin(ctx, "pair_rows");
                 hipLaunchKernelGGL(k_pair_rows_fused, dim3(pf_tiles), dim3(PF_THREADS), 0, ctx->stream, (const u64 *)pk, n_pairs, H->d_qid, H->d_tid,
-                                   H->d_isect, (unsigned long long *)H->d_nw, tbits, abits, (u32)rows_cap, pf_status, pf_ticket, d_nrows,
+                                   H->d_isect, (unsigned long long *)H->d_nw, tbits, abits, (u32)rows_cap, pf_status, pf_ticket, nrows_dev,
                                    (ctx->rows_use_ticket || getenv("KS_DEBUG_ROWS_TICKET")) ? 1 : 0);
                 ks_timer_end(ctx);
-                SE_HIP(hipMemcpyAsync(ctx->h_pin + 1, pf_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+                SE_HIP(hipMemcpyAsync(ctx->h_pin + 1, pf_ticket, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream)); // ticket pair + row count
             } else {
                 ks_timer_begin(ctx, "pair_reduce");
                 hipLaunchKernelGGL(k_pair_reduce, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv, (const u32 *)heads,
@@ -1383,7 +1386,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 ks_timer_end(ctx);
             }
             SE_HIP(hipGetLastError());
-            SE_HIP(hipMemcpyAsync(ctx->h_pin, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+            if (!fused) SE_HIP(hipMemcpyAsync(ctx->h_pin + 2, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
             SE_CHECK(ks_scan_status_fetch(ctx));
             SE_HIP(hipStreamSynchronize(ctx->stream));
             SE_CHECK(ks_scan_status_check(ctx));
@@ -1394,7 +1397,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 ctx->rows_use_ticket = true; // dispatch order did not hold here: tickets from now on
                 ctx->rows_ticket_fallbacks++;
             } else {
-                n_rows = *(u32 *)ctx->h_pin;
+                n_rows = *(u32 *)(ctx->h_pin + 2); // (fused: third word of the block copied to h_pin + 1; else copied there)
                 if (n_rows <= rows_cap) break;
                 rows_cap = n_rows;
             }
@@ -1412,7 +1415,7 @@ done:
     ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
     ks_pool_free(ctx, pk0); ks_pool_free(ctx, pk1); ks_pool_free(ctx, pv0); ks_pool_free(ctx, pv1);
     ks_pool_free(ctx, heads); ks_pool_free(ctx, d_nrows); ks_pool_free(ctx, row_start); ks_pool_free(ctx, cursor);
-    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, bcur); ks_pool_free(ctx, pf_status);
+    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, pf_status);
     if (st != KS_OK || split) { (void)hipStreamSynchronize(ctx->stream); ks_hits_free(H); return st; }
     *out = H;
     return KS_OK;
