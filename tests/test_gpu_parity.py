@@ -749,3 +749,37 @@ def test_row_pass_repeats_with_ticket_ids_when_a_lookback_gives_up(monkeypatch):
             assert np.array_equal(x, y) and np.array_equal(x, z)
     finally:
         c.close()
+
+
+def test_join_kernels_agree_on_heavily_repeated_hashes(ctx, monkeypatch):
+    """7,000 copies of one protein in the index and 300 copies of it among the queries: every hash of that protein has 7,000
+    postings (buckets beyond one LDS stage / one register pass: the chunk loops) and 300 query postings (candidate lists that
+    overflow: the per-lane paths).  All three join kernels must return the same rows as the oracle."""
+    rng = np.random.default_rng(18)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    prot = bytes(rng.choice(aa, size=80).tolist())
+    other = [bytes(rng.choice(aa, size=int(n)).tolist()) for n in rng.integers(50, 400, 300)]
+    t_res, t_off = ks.pack([prot] * 7000 + other)
+    q_res, q_off = ks.pack([prot] * 300 + other[:100] + [prot[:40]])
+    k, scaled, mol = 10, 1, "protein"
+    wt = oracle.sketch_batch(t_res, t_off, k, scaled, mol, n_threads=8)
+    wq = oracle.sketch_batch(q_res, q_off, k, scaled, mol, n_threads=8)
+    want = oracle.manysearch(wq[0], wq[1], wt[0], wt[1], wt[2], n_threads=8)
+    assert len(want[0]) > 300 * 7000
+    T = ctx.sketch_batch(t_res, t_off, k, scaled, mol)
+    Q = ctx.sketch_batch(q_res, q_off, k, scaled, mol)
+    for label, env in (("key columns", {}), ("fingerprints, staged index", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "0"}),
+                       ("fingerprints, query table", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "1"}),
+                       ("fingerprints, query table, segments", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "1", "KS_DEBUG_JOIN_SEGS": "1"}),
+                       ("fingerprints, staged index, segments, coarse", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "0", "KS_DEBUG_JOIN_SEGS": "1",
+                                                                        "KS_DEBUG_FP_COARSEN": "16"})):
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        ix = ctx.index_build(T)
+        hits = ctx.search(ix, Q)
+        got = hits.to_host()
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), label
+        hits.free(); ix.free()
+        for kk in env:
+            monkeypatch.delenv(kk)
