@@ -95,6 +95,7 @@ struct sk_args {
     u32 *ticket;    // [0] dynamic tile id, [1] status bits: 1 = a bounded spin expired, 2 = postings not emitted for some tile,
                     //     4 = a compacting tile kept more hashes (or holds more sequences) than its LDS lists take
     u32 n_tiles;
+    const u32 *n_tiles_dev; // MODE 0, optional: the tiles there really are (a launch sized by an upper bound: the rest return)
     // optional: postings (hash, sequence) partitioned on the low 8 bits of the join prefix into <= 256 fixed-capacity
     // regions, written while the vector ALU is the bottleneck — the query side's first partition pass of ks_search
     u64 *part_keys;   // [256 * part_cap] or NULL
@@ -864,6 +865,7 @@ __global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A)
             __syncthreads(); // the next sequence re-initialises the LDS state
         }
     } else {
+        if (A.n_tiles_dev && blockIdx.x >= *A.n_tiles_dev) return; // (uniform)
         sk_tile_body<MODE, CMP>(A, blockIdx.x);
     }
 }
@@ -1394,7 +1396,12 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     const bool planned = max_seq_len > 0 && !getenv("KS_DEBUG_NO_PLAN");
     u32 *pk_tiles = nullptr, *pk_cnt = nullptr, *d_ntiles = nullptr;
     u64 *tile_g0 = nullptr;
-    u64 pk_n_tiles = 0; // packed plan: tiles of the batch (read back with the statistics)
+    u64 pk_n_tiles = 0; // packed plan: tiles of the batch (read back with the statistics, or an upper bound: pk_bound)
+    // Packed plan without the round trip: with every sequence <= L = max_seq_len <= PK_MAX_LEN a tile is closed by a sequence
+    // that does not fit, so it holds more than SK_MED_MAX - 15 - L residues (one short tile per chunk besides): when that bound
+    // is within 2x of the typical count, the launch takes it as its grid and the tiles beyond the device-side count return at
+    // once.  (Worth ~20 us per call: small batches; a 1M-protein launch would not notice either way.)
+    u64 pk_bound = 0;
     // compacting variant: bucket space = positions / c_div, span = residues per shared tile (see k_sketch_tiles<0, 1>)
     const bool compact = (variant & 1) && p->scaled >= 2 && !getenv("KS_DEBUG_NO_COMPACT");
     const u32 c_div = compact ? (p->scaled < 64 ? p->scaled : 64u) : 1u;
@@ -1455,7 +1462,18 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
         }
-        if (!planned || packed) {
+        if (packed && planned && max_seq_len <= PK_MAX_LEN && !getenv("KS_DEBUG_PLAN_SYNC")) {
+            const u64 b = n_res / (SK_MED_MAX - 15 - max_seq_len + 1) + pk_chunks + 1;
+            const u64 typical = n_res / 3800 + pk_chunks + 1;
+            if (b <= 2 * typical + 256 && b <= n_seqs) pk_bound = b;
+            else if (n_seqs <= 2 * typical + 256) pk_bound = n_seqs; // (a tile holds at least one sequence)
+        }
+        if (pk_bound) {
+            real_max = max_seq_len;
+            win_bound = n_res;
+            tile_R = 0; n_med = 0; n_long = 0; // nothing is deferred: every sequence fits a tile
+            pk_n_tiles = pk_bound;
+        } else if (!planned || packed) {
             // no upper bound on the sequence length from the caller: the plan (tile stride, deferred sequences, slab size)
             // comes from the batch itself, at the price of one device -> host round trip before the tiles are launched
             SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, SK_CTL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
@@ -1602,6 +1620,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         if (compact) { A.c_div = c_div; A.c_rcp = (u32)(((1ULL << 32) + c_div - 1) / c_div); }
         A.out_hash = S->d_hashes; A.out_abund = S->d_abunds; A.csr = S->d_offsets;
         A.tile_status = tile_status; A.n_tiles = (u32)n_tiles;
+        A.n_tiles_dev = pk_bound ? d_ntiles : nullptr;
         // posting cursors as the medium tiles left them (a repeated launch starts from here)
         if (A.part_cursor && n_med > 0) { // (without medium tiles the cursors are still zero: a repeat just clears them)
             SK_CHECK(ks_alloc(ctx, &part_snap, 2048));
