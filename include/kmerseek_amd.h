@@ -247,6 +247,10 @@ int ks_hits_copy_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qid_base, uin
 int ks_hits_pack64_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qid_base, uint32_t tid_base, int qbits, int tbits,
                              uint64_t *d_packed, uint32_t *d_esc_row, uint32_t *d_esc_intersect, uint64_t *d_esc_n_weighted,
                              uint32_t *d_n_esc, uint32_t esc_cap);
+/* The receiving side: n transport words (device) -> the four columns (device, caller-owned).  Escaped rows come out with
+ * all-ones in both value fields; the caller patches them from the gathered escape lists.  Asynchronous on ctx's stream. */
+int ks_hits_unpack64_device(ks_ctx *ctx, const uint64_t *d_packed, uint64_t n, int qbits, int tbits, uint32_t *d_qid,
+                            uint32_t *d_tid, uint32_t *d_intersect, uint64_t *d_n_weighted);
 void ks_hits_free(ks_hits *h);
 
 /* ---- measurement --------------------------------------------------------------------------- */

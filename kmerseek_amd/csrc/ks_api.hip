@@ -311,6 +311,32 @@ extern "C" int ks_hits_pack64_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t 
     return KS_OK;
 }
 
+// the inverse, for the receiving side of the exchange: words -> columns (escaped rows keep the all-ones markers: the caller
+// patches them from the escape lists)
+__global__ __launch_bounds__(256) void k_hits_unpack64(const u64 *packed, u64 n, int qbits, int tbits, int vbits, u32 *qid, u32 *tid,
+                                                       u32 *isect, u64 *nw) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 w = packed[i], vmax = (1ULL << vbits) - 1ULL;
+    qid[i] = (u32)((w >> (tbits + 2 * vbits)) & ((1ULL << qbits) - 1ULL));
+    tid[i] = (u32)((w >> (2 * vbits)) & ((1ULL << tbits) - 1ULL));
+    isect[i] = (u32)((w >> vbits) & vmax);
+    nw[i] = w & vmax;
+}
+
+extern "C" int ks_hits_unpack64_device(ks_ctx *ctx, const uint64_t *d_packed, uint64_t n, int qbits, int tbits, uint32_t *d_qid,
+                                       uint32_t *d_tid, uint32_t *d_intersect, uint64_t *d_n_weighted) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (qbits < 1 || tbits < 1 || qbits + tbits > 48) return ks_fail(ctx, KS_ERR_INVALID_ARG, "unpack64: %d + %d id bits leave fewer than 8 value bits", qbits, tbits);
+    if (n == 0) return KS_OK;
+    if (!d_packed || !d_qid || !d_tid || !d_intersect || !d_n_weighted) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    if (n > 0xffffffffULL * 256ULL) return ks_fail(ctx, KS_ERR_INVALID_ARG, "unpack64: too many rows");
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    KS_LAUNCH(ctx, "hits_unpack", k_hits_unpack64, (u32)((n + 255) / 256), 256, (const u64 *)d_packed, n, qbits, tbits, (64 - qbits - tbits) / 2,
+              d_qid, d_tid, d_intersect, (u64 *)d_n_weighted);
+    return KS_OK;
+}
+
 extern "C" void ks_hits_free(ks_hits *h) {
     if (!h) return;
     ks_pool_free(h->ctx, h->d_qid);

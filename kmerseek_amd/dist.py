@@ -202,11 +202,26 @@ def _gather_packed(hits, on_device, n_local, counts, qid_base, tid_base, qbits, 
     n_esc = [int(x) for x in torch.stack([b[cap] for b in blocks]).tolist()]
     if max(n_esc) > esc_cap:
         return None
-    w = torch.cat([b[:c] for b, c in zip(blocks, counts)])
-    qid = ((w >> (tbits + 2 * v)) & ((1 << qbits) - 1)).to(torch.int32)
-    tid = ((w >> (2 * v)) & ((1 << tbits) - 1)).to(torch.int32)
-    isect = ((w >> v) & vmax).to(torch.int32)
-    nw = w & vmax
+    total = sum(counts)
+    if on_device and total:
+        # one native pass per shard straight into the gathered columns (instead of a concatenation and a dozen elementwise
+        # kernels over the whole list)
+        ctx = hits._ctx
+        qid = torch.empty(total, dtype=torch.int32, device=dev); tid = torch.empty(total, dtype=torch.int32, device=dev)
+        isect = torch.empty(total, dtype=torch.int32, device=dev); nw = torch.empty(total, dtype=torch.int64, device=dev)
+        at = 0
+        for b, c in zip(blocks, counts):
+            if c:
+                ctx.unpack_hits64_device(b.data_ptr(), c, qbits, tbits, qid.data_ptr() + 4 * at, tid.data_ptr() + 4 * at,
+                                         isect.data_ptr() + 4 * at, nw.data_ptr() + 8 * at)
+            at += c
+        own_stream_sync()
+    else:
+        w = torch.cat([b[:c] for b, c in zip(blocks, counts)])
+        qid = ((w >> (tbits + 2 * v)) & ((1 << qbits) - 1)).to(torch.int32)
+        tid = ((w >> (2 * v)) & ((1 << tbits) - 1)).to(torch.int32)
+        isect = ((w >> v) & vmax).to(torch.int32)
+        nw = w & vmax
     off = 0
     for b, c, ne in zip(blocks, counts, n_esc):
         if ne:

@@ -151,6 +151,11 @@ class Context:
         self._check(self._L.ks_ctx_sketch_stats(self._h, C.byref(v)))
         return {"ticket_fallbacks": int(v[0]), "uses_ticket": int(v[1]), "compact_fallbacks": int(v[2]), "cap_fallbacks": int(v[3])}
 
+    def unpack_hits64_device(self, d_packed: int, n: int, qbits: int, tbits: int, d_qid: int, d_tid: int, d_isect: int, d_nw: int):
+        """Transport words -> columns, all device pointers (ks_hits_unpack64_device): the receiving side of the exchange."""
+        self._check(self._L.ks_hits_unpack64_device(self._h, C.c_void_p(d_packed), n, qbits, tbits, C.c_void_p(d_qid), C.c_void_p(d_tid),
+                                                    C.c_void_p(d_isect), C.c_void_p(d_nw)))
+
     def search_stats(self) -> Dict[str, int]:
         """Repeats ks_search needed so far on this context (see ks_ctx_search_stats)."""
         v = (C.c_uint64 * 2)()

@@ -159,3 +159,22 @@ def test_dist_layer_single_rank_gpu(ctx):
         assert np.array_equal(((w >> (2 * v)) & ((1 << tbits) - 1)).cpu().numpy(), want[1].astype(np.int64) + 9)
         assert np.array_equal(isect, want[2].astype(np.uint64)) and np.array_equal(nw, want[3])
     assert int(want[2].max()) >= 255  # (24 + 24 id bits leave 8 value bits: the related pairs escape)
+    # the receiving side on the device (ks_hits_unpack64_device inside dist._gather_packed), with a stand-in for the
+    # collective: two ranks that hold this same shard
+    class _TwoRanks:
+        @staticmethod
+        def all_gather_into_tensor(recv, send):
+            half = send.numel()
+            recv[:half] = send
+            recv[half:2 * half] = send
+    real = ksd._dist
+    ksd._dist = lambda: _TwoRanks
+    try:
+        for qbits, tbits in ((12, 12), (24, 24)):
+            out = ksd._gather_packed(h, True, n, [n, n], 7, 9, qbits, tbits, dev, ctx.synchronize)
+            assert out is not None
+            for col, w_, add, dt in zip(out, want, (7, 9, 0, 0), (np.uint32, np.uint32, np.uint32, np.uint64)):
+                got_col = col.cpu().numpy().view(dt)
+                assert np.array_equal(got_col[:n], w_.astype(dt) + dt(add)) and np.array_equal(got_col[n:], w_.astype(dt) + dt(add))
+    finally:
+        ksd._dist = real
