@@ -482,8 +482,8 @@ KS_DEV void jn_confirm_slow(const ks_post *post, u32 p0, u32 c, u64 h, u32 *firs
 // Per round of JN_THREADS*JN_E query postings: every thread searches the staged fingerprints for its queries (LDS only);
 // the candidates of a wave — a few per cent of its queries, anywhere among a thread's JN_E slots — are LISTED in LDS
 // (query slot, index posting, full hash), so that lane k confirms and emits candidate k: one 16-byte posting fetch and one
-// qid fetch per candidate in full lanes, the confirmed ones ranked by a block scan, ONE device-wide atomic reserving the
-// round's slice of the pair list, contiguous stores.
+// qid fetch per candidate in full lanes, the confirmed ones ranked by a wave scan (segmented pair list: one reservation per
+// wave on the segment's cursor) or a block scan (one cursor: one reservation per workgroup round), contiguous stores.
 __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_join_buckets(
     const u64 *qkeys, const u32 *qids, const u32 *ifp, const ks_post *ipost, const ks_bmeta *bmeta, const u64 *q_lo, const u64 *q_hi,
     const u64 *dir_t, u64 *pair_keys, u32 *pair_vals, u64 cap, unsigned long long *cursors, u32 seg_mask, int tbits, int abits,
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
                 const u32 i = (u32)e * JN_THREADS + tid;
                 info[e] = 0;
                 // (uniform: a bucket with few query postings — small batches, query shards of a strong-scaling run — fills
-                // only the first slots of the round, and an empty slot would cost the same 13 LDS probes as a full one)
+                // only the first slots of the round, and an empty slot would cost the same directory reads and probes as a full one)
                 if ((u32)e * JN_THREADS >= nq) continue;
                 const u32 f = jn_fingerprint(h[e], kbase, fp_shift);
                 const u32 sl = jn_slot(f, dirM);
