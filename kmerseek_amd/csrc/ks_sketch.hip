@@ -1107,6 +1107,7 @@ struct kp_args {
     u64 *out_hash;
     u64 n_res, max_hash, seed;
     u32 n_seqs, k, n_tiles;
+    u32 use_ticket;                 // tile ids from the atomic ticket (1) or from blockIdx.x (0), as in k_sketch_tiles
 };
 
 __global__ __launch_bounds__(256) void k_kmerpos_plan(const u64 *offs, u32 n_seqs, u32 n_tiles, u32 *tile_first) {
@@ -1126,8 +1127,10 @@ __global__ __launch_bounds__(SK_THREADS) void k_kmerpos_tiles(kp_args A) {
     __shared__ unsigned long long base_s;
     const u32 tid = threadIdx.x;
     constexpr u32 NCH = (SK_TILE + SK_PAD) / 16;
-    u32 ticket_v = 0;
-    if (tid == 0) ticket_v = atomicAdd(&A.ticket[0], 1u);
+    // (tile ids in dispatch order; a launch whose look-back gave up is repeated with ticket ids: 73k tickets on one address
+    // were 0.9 ms of queueing for a 1M-protein batch)
+    u32 ticket_v = blockIdx.x;
+    if (A.use_ticket && tid == 0) ticket_v = atomicAdd(&A.ticket[0], 1u);
     if (tid < 256) lut_s[tid] = A.lut[tid];
     if (tid == 0) tile_s = ticket_v;
     __syncthreads();
@@ -1286,31 +1289,37 @@ int ks_kmerpos_tiles_launch(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32
     if (st == KS_OK) st = ks_alloc(ctx, &ticket, 2);
     if (st == KS_OK) st = ks_alloc(ctx, &total, 1);
     if (st == KS_OK) {
-        (void)hipMemsetAsync(status, 0, (size_t)n_tiles * sizeof(u64), ctx->stream);
-        (void)hipMemsetAsync(ticket, 0, 2 * sizeof(u32), ctx->stream);
-        (void)hipMemsetAsync(total, 0, sizeof(u64), ctx->stream);
         ks_timer_begin(ctx, "kmerpos_plan");
         hipLaunchKernelGGL(k_kmerpos_plan, dim3((n_tiles + 256) / 256), dim3(256), 0, ctx->stream, d_offs, n_seqs, n_tiles, tile_first);
         ks_timer_end(ctx);
+    }
+    for (int attempt = 0; st == KS_OK && attempt < 2; attempt++) {
+        const bool use_ticket = ctx->sketch_use_ticket || attempt == 1;
+        (void)hipMemsetAsync(status, 0, (size_t)n_tiles * sizeof(u64), ctx->stream);
+        (void)hipMemsetAsync(ticket, 0, 2 * sizeof(u32), ctx->stream);
+        (void)hipMemsetAsync(total, 0, sizeof(u64), ctx->stream);
         kp_args A;
         memset(&A, 0, sizeof A);
         A.res = d_res; A.offs = d_offs; A.lut = ctx->d_lut + 256 * p->moltype; A.tile_first = tile_first;
         A.tile_status = status; A.ticket = ticket; A.total = total; A.out_seq = d_seq; A.out_start = d_start; A.out_hash = d_hash;
         A.n_res = n_res; A.max_hash = ks_max_hash(p->scaled); A.seed = p->seed; A.n_seqs = n_seqs; A.k = p->ksize; A.n_tiles = n_tiles;
+        A.use_ticket = use_ticket ? 1u : 0u;
         ks_timer_begin(ctx, "kmerpos_tiles");
         hipLaunchKernelGGL(k_kmerpos_tiles, dim3(n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
         ks_timer_end(ctx);
-        if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "k-mer position launch failed");
-    }
-    if (st == KS_OK) {
+        if (hipGetLastError() != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "k-mer position launch failed"); break; }
         if (hipMemcpyAsync(ctx->h_pin, total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(ctx->h_pin + 1, ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
             st = ks_fail(ctx, KS_ERR_HIP, "k-mer position status read failed");
-        else if (((u32 *)(ctx->h_pin + 1))[1] != 0)
-            st = ks_fail(ctx, KS_ERR_HIP, "k-mer positions: look-back gave up waiting for a predecessor tile");
-        else
-            *n_out = ctx->h_pin[0];
+            break;
+        }
+        bool gave_up = ((u32 *)(ctx->h_pin + 1))[1] != 0;
+        if (!use_ticket && getenv("KS_DEBUG_FORCE_TICKET_RETRY")) gave_up = true; // exercises the repeat
+        if (!gave_up) { *n_out = ctx->h_pin[0]; break; }
+        if (use_ticket) { st = ks_fail(ctx, KS_ERR_HIP, "k-mer positions: look-back gave up waiting for a predecessor tile"); break; }
+        ctx->sketch_use_ticket = true; // dispatch order did not hold here: tickets from now on (shared with the sketch tiles)
+        ctx->sketch_ticket_fallbacks++;
     }
     ks_pool_free(ctx, tile_first); ks_pool_free(ctx, status); ks_pool_free(ctx, ticket); ks_pool_free(ctx, total);
     return st;

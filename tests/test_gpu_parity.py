@@ -535,6 +535,21 @@ def test_sketch_repeats_with_ticket_ids_when_a_lookback_gives_up(monkeypatch):
             assert np.array_equal(g, w)
     finally:
         ctx.close()
+    # the k-mer position tiles share the scheme: dispatch-order ids, forced repeat with tickets, tickets from then on
+    ctx = ks.Context(0)
+    try:
+        a = ctx.kmer_positions(q_res, q_off, 10, 1, "protein")
+        assert ctx.sketch_stats()["ticket_fallbacks"] == 0
+        monkeypatch.setenv("KS_DEBUG_FORCE_TICKET_RETRY", "1")
+        b = ctx.kmer_positions(q_res, q_off, 10, 1, "protein")
+        monkeypatch.delenv("KS_DEBUG_FORCE_TICKET_RETRY")
+        assert ctx.sketch_stats()["ticket_fallbacks"] == 1 and ctx.sketch_stats()["uses_ticket"] == 1
+        c = ctx.kmer_positions(q_res, q_off, 10, 1, "protein")
+        for x, y, z in zip(a, b, c):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+        assert len(a[0]) == int((np.maximum((q_off[1:] - q_off[:-1]).astype(np.int64) - 9, 0)).sum())
+    finally:
+        ctx.close()
 
 
 def test_max_seq_len_plan_equals_measured_plan(ctx):
