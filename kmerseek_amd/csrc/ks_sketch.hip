@@ -41,6 +41,9 @@ static const u32 sk_r_cand_host[SK_NR] = {2544, 2800, 3056, 3312, 3568, 3824, 39
 #define SK_MINW 6                   // waves per SIMD to compile for: 3 workgroups of 8 waves per CU
 #endif
 #define SK_NFLAG (SK_TILE / 32)
+#ifndef SK_QUEUE_RES
+#define SK_QUEUE_RES 1
+#endif
 
 // Diagnostic build only (-DSK_STAMP): per-phase shader-clock shares of k_sketch_tiles, summed over
 // workgroups by lane 0.  Never compiled into the shipped library; the numbers are shares, not times.
@@ -576,8 +579,16 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     // LDS read.  The rest ("heavy": bucket of 3+) would make every wave iterate to ITS largest bucket in each of the
     // 8 slots, so they are queued (in the unused tail of tmp) and ranked by all threads evenly in a second pass.
     const u32 n_kept = bstart(SK_TILE);
+#if SK_QUEUE_RES
+    // (the queue lives in the residue buffer, dead since the hash phase — the compacting variant keeps its bucket table in the
+    // first 2 KB of it.  The unused tail of tmp, where it used to be, holds a few hundred entries in a packed tile, 95 % full:
+    // most heavy elements then found no room and were ranked in place, every wave iterating to its largest bucket)
+    u32 *queue = (u32 *)res_w + (CMP ? 512 : 0);
+    const u32 qcap = (SK_TILE + SK_PAD) / 4 - (CMP ? 512 : 0);
+#else
     u32 *queue = (u32 *)(tmp + n_kept);
     const u32 qcap = (SK_TILE - n_kept) * 2;
+#endif
     u32 eidx[SK_E / 2]; // queue slot of a heavy element, 16 bits per slot (0xffff = none)
 #pragma unroll
     for (int i = 0; i < SK_E / 2; i++) eidx[i] = 0xffffffffu;
