@@ -581,10 +581,11 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     const u32 n_kept = bstart(SK_TILE);
 #if SK_QUEUE_RES
     // (the queue lives in the residue buffer, dead since the hash phase — the compacting variant keeps its bucket table in the
-    // first 2 KB of it.  The unused tail of tmp, where it used to be, holds a few hundred entries in a packed tile, 95 % full:
+    // first 8 bytes per sequence of it.  The unused tail of tmp, where it used to be, holds a few hundred entries in a packed tile, 95 % full:
     // most heavy elements then found no room and were ranked in place, every wave iterating to its largest bucket)
-    u32 *queue = (u32 *)res_w + (CMP ? 512 : 0);
-    const u32 qcap = (SK_TILE + SK_PAD) / 4 - (CMP ? 512 : 0);
+    const u32 q_skip = CMP ? 2u * (ns < SK_SEQ_CAP + 1u ? ns : SK_SEQ_CAP + 1u) : 0u; // (8 bytes of bucket table per sequence)
+    u32 *queue = (u32 *)res_w + q_skip;
+    const u32 qcap = (SK_TILE + SK_PAD) / 4 - q_skip;
 #else
     u32 *queue = (u32 *)(tmp + n_kept);
     const u32 qcap = (SK_TILE - n_kept) * 2;
