@@ -41,9 +41,8 @@ static const u32 sk_r_cand_host[SK_NR] = {2544, 2800, 3056, 3312, 3568, 3824, 39
 #define SK_MINW 6                   // waves per SIMD to compile for: 3 workgroups of 8 waves per CU
 #endif
 #define SK_NFLAG (SK_TILE / 32)
-#ifndef SK_QUEUE_RES
-#define SK_QUEUE_RES 1
-#endif
+#define SK_C3MAX 32u                // a bucket of more hashes than this is put in order by the whole workgroup
+#define SK_QB_CAP 128u              // >= SK_TILE / (SK_C3MAX + 1): list of those buckets (16-bit entries)
 
 // Diagnostic build only (-DSK_STAMP): per-phase shader-clock shares of k_sketch_tiles, summed over
 // workgroups by lane 0.  Never compiled into the shipped library; the numbers are shares, not times.
@@ -151,6 +150,43 @@ KS_DEV u64 sk_hash_window(const u64 *w /* LDS words starting at pos8 */, u32 k, 
 KS_DEV bool sk_deferred(u64 start, u64 len, u32 R, u32 span) { return start % R + len > span - 16; }
 // floor(x / d) for x < 2^32 / d with rcp = ceil(2^32 / d) (d = 1: rcp does not fit, handled apart)
 KS_DEV u32 sk_div(u32 x, u32 d, u32 rcp) { return d == 1 ? x : __umulhi(x, rcp); }
+
+// Block-wide exclusive scan of two values at once (SK_THREADS threads; `smem` holds 2 * (SK_THREADS / 64 + 1) words).
+KS_DEV u32 sk_block_excl_scan2(u32 a, u32 b, u32 *smem, u32 *total_a, u32 *excl_b) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr u32 NW = SK_THREADS / 64;
+    u32 ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
+        if (lane >= (u32)d) { ia += ta; ib += tb; }
+    }
+    if (lane == 63) { smem[wave] = ia; smem[NW + 1 + wave] = ib; }
+    __syncthreads();
+    u32 base_a = 0, base_b = 0, tot_a = 0, tot_b = 0;
+#pragma unroll
+    for (u32 wv = 0; wv < NW; wv++) { // (8 wave totals: every thread sums them itself — no second barrier)
+        const u32 va = smem[wv], vb = smem[NW + 1 + wv];
+        base_a += wv < wave ? va : 0u; base_b += wv < wave ? vb : 0u;
+        tot_a += va; tot_b += vb;
+    }
+    *total_a = tot_a;
+    *excl_b = base_b + ib - b;
+    if (threadIdx.x == 0) smem[NW] = tot_b; // tile totals of b for whoever reads them after the caller's next barrier
+    return base_a + ia - a;
+}
+
+// ... and of one value, with ONE barrier (the caller's next barrier must come before scan_smem is written again)
+KS_DEV u32 sk_block_excl_scan1(u32 a, u32 *smem) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 ia = ks_wave_incl_scan(a);
+    if (lane == 63) smem[wave] = ia;
+    __syncthreads();
+    u32 base = 0;
+#pragma unroll
+    for (u32 wv = 0; wv < SK_THREADS / 64; wv++) base += wv < wave ? smem[wv] : 0u;
+    return base + ia - a;
+}
 
 #define SK_CTL_WORDS 32 // control block of a sketch call (see sketch_attempt)
 #define SK_SEQ_CAP 254 // sequence boundaries of a tile staged in LDS (tiles with more fall back to global reads)
@@ -340,9 +376,11 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     __shared__ __attribute__((aligned(16))) u64 tmp[SK_TILE];
     __shared__ u32 flagbits[SK_NFLAG];
     __shared__ u32 flagpre[SK_NFLAG + 1];
-    __shared__ u32 scan_smem[SK_THREADS / 64 + 1];
+    __shared__ u32 scan_smem[2 * (SK_THREADS / 64 + 1)];
     __shared__ u32 loff[SK_SEQ_CAP + 2];
     __shared__ u8 lut_s[256];
+    __shared__ u32 bins[256];  // postings: count per digit, then the digit's start inside the tile
+    __shared__ u32 gbase[256]; // postings: the tile's slice of each digit's region
 
     const u32 tid = threadIdx.x;
     u8 *res_b = (u8 *)res_w;
@@ -353,7 +391,6 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     // ---- phase 0: tile -> sequence range (planned ahead), zero LDS state, stage LUT + sequence boundaries
     __shared__ u32 tile_s;
     __shared__ u32 ext_n;
-    __shared__ u32 ext_n_heavy; // heavy-bucket queue cursor
     __shared__ u32 ext_seq[4], ext_cnt[4], ext_d[4];
     __shared__ unsigned long long base_s;
     u32 tile = tile_in;
@@ -369,14 +406,13 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     // into a flag, and the host then repeats the launch with ids drawn from an atomic ticket (use_ticket), which
     // guarantees the order by construction.
     if (MODE == 0 && tid == 0) ticket_v = A.use_ticket ? atomicAdd(&A.ticket[0], 1u) : tile_in;
-    if (tid < 256) lut_s[tid] = A.lut[tid];
+    if (tid < 256) { lut_s[tid] = A.lut[tid]; bins[tid] = 0; }
     for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
     if (tid < SK_NFLAG) flagbits[tid] = 0;
     __shared__ u32 n_list_s; // CMP: kept windows appended to the list so far
-    if (tid == 0) { ext_n_heavy = 0; ext_n = 0; n_list_s = 0; }
-    if (MODE == 0) {
+    if (tid == 0) { ext_n = 0; n_list_s = 0; }
+    if (MODE == 0 && A.use_ticket) { // (uniform)
         // tiles are handed out in ticket order, so every predecessor a look-back waits for is already running
-        // (this barrier also orders the LUT staged above before the threads that encode residues through it)
         if (tid == 0) tile_s = ticket_v;
         __syncthreads();
         tile = tile_s;
@@ -431,6 +467,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         }
         __syncthreads(); // lut_s
     }
+    if (MODE == 0) __syncthreads(); // the LUT and the zeroed LDS state (the tile's global loads are in flight)
     if (tid < NCH) stage_chunk(rv);
     __syncthreads();
 
@@ -546,138 +583,252 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     __syncthreads();
 
     SK_STAMP_AT(2);
-    // ---- phase 3: bucket counts -> bucket starts (exclusive scan over the tile)
+    // ---- phase 3: bucket counts -> bucket starts (exclusive scan over the tile).  The thread that scans a bucket knows its
+    // size: buckets that hold more than one hash are LISTED here and put in order in place by phase 5 — nothing is ranked
+    // element by element (that cost as much as hashing: 812 VALU instructions per wave against 796, profiles/r02_sq_counters.md).
+    // The lists live in the residue buffer, dead since the hash phase (the compacting variant keeps its bucket table in
+    // the first 8 bytes per sequence of it): 16-bit entries; qb = buckets of more than SK_C3MAX (never more than
+    // SK_TILE / (SK_C3MAX + 1) of them), q3 = buckets of 3 .. SK_C3MAX, q2 = pairs (entry = the pair's first position).
+    const u32 q_skip = CMP ? 2u * (ns < SK_SEQ_CAP + 1u ? ns : SK_SEQ_CAP + 1u) : 0u; // (8 bytes of bucket table per sequence)
+    u16 *qb = (u16 *)((u32 *)res_w + q_skip);
+    u16 *q3 = qb + SK_QB_CAP;
+    const u32 q_ents = ((SK_TILE + SK_PAD) / 4 - q_skip) * 2 - SK_QB_CAP;
+    const u32 q3cap = q_ents * 2 / 5, q2cap = q_ents - q3cap;
+    u16 *q2 = q3 + q3cap;
+    u32 ovf = 0; // my buckets that found no room in a list (bit layout of the class masks below): I put them in order myself
     {
-        u32 c[SK_E], s = 0;
         const uint4 w4 = *(const uint4 *)&cnt[q0 >> 1]; // 8 consecutive 16-bit counters
         const u32 w[4] = {w4.x, w4.y, w4.z, w4.w};
+        const u32 hs = w[0] + w[1] + w[2] + w[3]; // (both halves at once: a tile's counts sum to <= SK_TILE)
+        const u32 s = (hs & 0xffffu) + (hs >> 16);
+        // size classes of my 8 buckets, two counters per word at a time (counts <= SK_TILE, so no carry leaves a half):
+        // bit j = counter 2j, bit 16 + j = counter 2j + 1
+        u32 ge2 = 0, ge3 = 0, big = 0;
 #pragma unroll
-        for (int i = 0; i < SK_E; i++) { c[i] = (w[i >> 1] >> ((i & 1) * 16)) & 0xffffu; s += c[i]; }
-        u32 total;
-        u32 ex = ks_block_excl_scan(s, scan_smem, &total);
-        u32 o[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 4; j++) {
+            ge2 |= (((w[j] + 0x7ffe7ffeu) & 0x80008000u) >> 15) << j;
+            ge3 |= (((w[j] + 0x7ffd7ffdu) & 0x80008000u) >> 15) << j;
+            big |= (((w[j] + (0x8000u - SK_C3MAX - 1u) * 0x00010001u) & 0x80008000u) >> 15) << j;
+        }
+        u32 m2 = ge2 & ~ge3, m3 = ge3 & ~big;
+        const u32 code = (u32)__popc(m2) | ((u32)__popc(m3) << 12) | ((u32)__popc(big) << 24); // (tile totals fit the fields)
+        u32 total, at;
+        u32 ex = sk_block_excl_scan2(s, code, scan_smem, &total, &at);
+        u32 i2 = at & 0xfffu, i3 = (at >> 12) & 0xfffu, ib = at >> 24;
+        u32 o[4];
 #pragma unroll
-        for (int i = 0; i < SK_E; i++) { o[i >> 1] |= ex << ((i & 1) * 16); ex += c[i]; } // starts <= 4096 fit 16 bits
+        for (int j = 0; j < 4; j++) { // starts <= 4096 fit 16 bits
+            const u32 lo = w[j] & 0xffffu;
+            o[j] = ex | ((ex + lo) << 16);
+            ex += lo + (w[j] >> 16);
+        }
         *(uint4 *)&cnt[q0 >> 1] = make_uint4(o[0], o[1], o[2], o[3]);
         if (tid == SK_THREADS - 1) cnt[SK_TILE / 2] = total | (total << 16);
+        // list entries = bucket numbers
+        while (m2) {
+            const u32 bit = (u32)__builtin_ctz(m2);
+            m2 &= m2 - 1u;
+            if (i2 < q2cap) q2[i2] = (u16)(q0 + 2u * (bit & 15u) + (bit >> 4)); else ovf |= 1u << bit;
+            i2++;
+        }
+        while (m3) {
+            const u32 bit = (u32)__builtin_ctz(m3);
+            m3 &= m3 - 1u;
+            if (i3 < q3cap) q3[i3] = (u16)(q0 + 2u * (bit & 15u) + (bit >> 4)); else ovf |= 1u << bit;
+            i3++;
+        }
+        while (big) {
+            const u32 bit = (u32)__builtin_ctz(big);
+            big &= big - 1u;
+            qb[ib++] = (u16)(q0 + 2u * (bit & 15u) + (bit >> 4));
+        }
     }
     __syncthreads();
     // (the packed 16-bit starts read as a u16 array: one ds_read_u16 instead of read + shift + mask)
     auto bstart = [&](u32 b) -> u32 { return ((const u16 *)cnt)[b]; };
+    const u32 n_kept = bstart(SK_TILE);
 
     SK_STAMP_AT(3);
-    // ---- phase 4: scatter kept hashes into bucket order
+    // ---- phase 4: scatter kept hashes into bucket order; sorted position at which every sequence's run starts
 #pragma unroll
     for (int i = 0; i < SK_E; i++)
         if (bo[i] != 0xffffffffu) tmp[bstart(SK_BO_B(bo[i])) + SK_BO_O(bo[i])] = h[i];
+    if (B.in_lds)
+        for (u32 i = tid; i <= ns; i += SK_THREADS) // (first bucket of a sequence: its local start, or the compacted base of the bucket table)
+            dseq[i] = (u16)(i == ns ? n_kept : bstart(CMP ? ((const uint2 *)res_w)[i].x : loff[i]));
+    if (MODE == 0) // a deferred (medium / long) sequence that starts inside this tile (at most one: the last): its unique count is known
+        for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
+            const u32 ls = B.at(s), le = B.at(s + 1);
+            if (le > A.le_cap || le - ls > A.max_len_tile) {
+                const u32 e = atomicAdd(&ext_n, 1u);
+                if (e < 4) { ext_seq[e] = s; ext_cnt[e] = A.counts[s]; ext_d[e] = 0; }
+            }
+        }
+    else // (rare: more sequences than the LDS tables hold) the positions at which a run starts, as a bitmap for phase 6
+        for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
+            const u32 ls = B.at(s);
+            const u32 d = ls <= SK_TILE ? bstart(ls) : n_kept;
+            if (d < n_kept) atomicOr(&flagbits[d >> 5], 1u << (d & 31));
+        }
     __syncthreads();
 
     SK_STAMP_AT(4);
-    // ---- phase 5: rank inside the bucket; first arrival of each distinct hash is its representative
-    u32 pa[SK_E]; // abundance (later: rank inside the posting digit) << 16 | sorted position << 1 | is_representative; 0 = nothing
-    // Buckets hold ~1 element: 3 out of 4 kept hashes sit in a bucket of size 1 or 2 and are ranked with at most one
-    // LDS read.  The rest ("heavy": bucket of 3+) would make every wave iterate to ITS largest bucket in each of the
-    // 8 slots, so they are queued (in the unused tail of tmp) and ranked by all threads evenly in a second pass.
-    const u32 n_kept = bstart(SK_TILE);
-#if SK_QUEUE_RES
-    // (the queue lives in the residue buffer, dead since the hash phase — the compacting variant keeps its bucket table in the
-    // first 8 bytes per sequence of it.  The unused tail of tmp, where it used to be, holds a few hundred entries in a packed tile, 95 % full:
-    // most heavy elements then found no room and were ranked in place, every wave iterating to its largest bucket)
-    const u32 q_skip = CMP ? 2u * (ns < SK_SEQ_CAP + 1u ? ns : SK_SEQ_CAP + 1u) : 0u; // (8 bytes of bucket table per sequence)
-    u32 *queue = (u32 *)res_w + q_skip;
-    const u32 qcap = (SK_TILE + SK_PAD) / 4 - q_skip;
-#else
-    u32 *queue = (u32 *)(tmp + n_kept);
-    const u32 qcap = (SK_TILE - n_kept) * 2;
-#endif
-    u32 eidx[SK_E / 2]; // queue slot of a heavy element, 16 bits per slot (0xffff = none)
-#pragma unroll
-    for (int i = 0; i < SK_E / 2; i++) eidx[i] = 0xffffffffu;
-    auto rank_in_bucket = [&](u32 sb, u32 c, u32 o, u64 hh, u32 &p, u32 &eq, u32 &rep) {
-        u32 less = 0, eqb = 0;
-        eq = 0;
-        for (u32 j = 0; j < c; j++) {
-            const u64 x = tmp[sb + j];
-            less += x < hh;
-            eq += x == hh;
-            eqb += (x == hh) & (j < o);
-        }
-        p = sb + less + eqb;
-        rep = eqb == 0;
-    };
-#pragma unroll
-    for (int i = 0; i < SK_E; i++) {
-        pa[i] = 0;
-        if (bo[i] != 0xffffffffu) {
-            const u32 b = SK_BO_B(bo[i]), o = SK_BO_O(bo[i]);
-            const u32 sb = bstart(b), c = bstart(b + 1) - sb;
-            u32 p = sb, eq = 1, rep = 1;
-            bool done = true;
-            if (c == 2) {
-                const u64 x = tmp[sb + (o ^ 1u)];
-                const u32 same = x == h[i];
-                p = sb + (x < h[i]) + (same & (o == 1u));
-                eq = 1 + same;
-                rep = !(same & (o == 1u));
-            } else if (c > 2) {
-                const u32 e = atomicAdd(&ext_n_heavy, 1u);
-                if (e < qcap && e < 0xffffu) {
-                    queue[e] = b | (o << 12);
-                    eidx[i >> 1] = (eidx[i >> 1] & ~(0xffffu << ((i & 1) * 16))) | (e << ((i & 1) * 16));
-                    done = false;
-                } else {
-                    rank_in_bucket(sb, c, o, h[i], p, eq, rep); // no queue room (tile nearly full): rank in place
-                }
+    // ---- phase 5: put the listed buckets in order, in place.  tmp then holds the tile's kept hashes sorted by
+    // (sequence, hash): equal hashes of a sequence are neighbours.
+    auto sort_small = [&](u32 sb, u32 c) { // insertion sort of tmp[sb, sb + c)
+        for (u32 a = 1; a < c; a++) {
+            const u64 x = tmp[sb + a];
+            u32 j = a;
+            while (j > 0) {
+                const u64 y = tmp[sb + j - 1];
+                if (y <= x) break;
+                tmp[sb + j] = y;
+                j--;
             }
-            if (done) pa[i] = (eq << 16) | (p << 1) | rep; // eq <= 4096 windows of a tile
+            if (j != a) tmp[sb + j] = x;
         }
-    }
-    __syncthreads();
+    };
     {
-        u32 nq = ext_n_heavy;
-        if (nq > qcap) nq = qcap;
-        if (nq > 0xffffu) nq = 0xffffu;
-        for (u32 e = tid; e < nq; e += SK_THREADS) {
-            const u32 code = queue[e], b = code & 0xfffu, o = code >> 12;
-            const u32 sb = bstart(b), c = bstart(b + 1) - sb;
-            u32 p, eq, rep;
-            rank_in_bucket(sb, c, o, tmp[sb + o], p, eq, rep);
-            queue[e] = p | (rep << 12) | (eq << 13);
+        const u32 qc = scan_smem[SK_THREADS / 64]; // list totals, left there by phase 3's scan
+        const u32 n2 = (qc & 0xfffu) < q2cap ? (qc & 0xfffu) : q2cap;
+        const u32 n3 = ((qc >> 12) & 0xfffu) < q3cap ? ((qc >> 12) & 0xfffu) : q3cap;
+        const u32 nb = qc >> 24;
+        for (u32 e = tid; e < n2; e += SK_THREADS) {
+            const u32 sb = bstart(q2[e]);
+            const u64 x = tmp[sb], y = tmp[sb + 1];
+            if (x > y) { tmp[sb] = y; tmp[sb + 1] = x; }
+        }
+        // (from the last thread down: the waves a second round of pairs keeps busy are the first ones)
+        for (u32 e = SK_THREADS - 1u - tid; e < n3; e += SK_THREADS) {
+            const u32 b = q3[e], sb = bstart(b);
+            sort_small(sb, bstart(b + 1) - sb);
+        }
+        while (ovf) { // (rare: a list was full)
+            const u32 bit = (u32)__builtin_ctz(ovf);
+            ovf &= ovf - 1u;
+            const u32 b = q0 + 2u * (bit & 15u) + (bit >> 4), sb = bstart(b);
+            sort_small(sb, bstart(b + 1) - sb);
+        }
+        if (nb) { // (uniform; rare) buckets of more than SK_C3MAX hashes — repeats inside a low-complexity sequence, mostly:
+                  // all threads rank one bucket's elements by counting (equal hashes keep their order), then move them
+            for (u32 e = 0; e < nb; e++) {
+                const u32 b = qb[e], sb = bstart(b), c = bstart(b + 1) - sb;
+                __syncthreads();
+                u64 xs[SK_E];
+                u32 rk[SK_E];
+#pragma unroll
+                for (int i = 0; i < SK_E; i++) {
+                    const u32 j = (u32)i * SK_THREADS + tid; // c <= SK_TILE = SK_E * SK_THREADS
+                    rk[i] = 0xffffffffu;
+                    if (j < c) {
+                        const u64 x = tmp[sb + j];
+                        u32 r = 0;
+                        for (u32 m = 0; m < c; m++) {
+                            const u64 y = tmp[sb + m];
+                            r += (y < x) | ((y == x) & (m < j));
+                        }
+                        xs[i] = x; rk[i] = r;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < SK_E; i++)
+                    if (rk[i] != 0xffffffffu) tmp[sb + rk[i]] = xs[i];
+            }
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < SK_E; i++) {
-        const u32 e = (eidx[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-        if (e != 0xffffu) {
-            const u32 r = queue[e];
-            pa[i] = ((r >> 13) << 16) | ((r & 0xfffu) << 1) | ((r >> 12) & 1u);
-        }
-    }
-    // Does any hash of this tile repeat inside its sequence?  For protein k-mers almost never (the 1M-protein batch: a
-    // handful of tiles), and then every kept hash is its own representative with abundance 1 and its distinct rank IS its
-    // sorted position: the flag / bit-prefix machinery below is only run by tiles that need it (low-complexity sequences,
-    // the reduced alphabets).
-    bool dup = false;
-#pragma unroll
-    for (int i = 0; i < SK_E; i++) dup |= pa[i] != 0 && (pa[i] & 0xffff0001u) != 0x00010001u; // not (abundance 1, representative)
-    const bool any_dup = __syncthreads_or(dup);
 
     SK_STAMP_AT(5);
-    // ---- phase 6: prefix over representative flags -> distinct rank
-    if (any_dup) { // (uniform)
+    // ---- phase 6: every thread takes 8 consecutive SORTED positions back into registers (the LDS buffers are reused below).
+    // A hash that equals its left neighbour inside the same sequence is a repeat: the first of a run is the representative,
+    // the run's length its abundance.
+    const u32 p0 = tid * SK_E;
+    u32 rep = 0;          // bit i: position p0 + i holds a representative
+    u32 live = 0;         // bit i: position p0 + i < n_kept
+    u32 srl[2] = {0, 0};  // sequence (relative to the tile's first) of each position, 8 bits each (tiles of <= SK_SEQ_CAP sequences)
+    bool dup = false;
+    if (p0 < n_kept) {
+        {
+            const uint4 a = *(const uint4 *)&tmp[p0], b = *(const uint4 *)&tmp[p0 + 2], c = *(const uint4 *)&tmp[p0 + 4],
+                        d = *(const uint4 *)&tmp[p0 + 6];
+            h[0] = (u64)a.x | ((u64)a.y << 32); h[1] = (u64)a.z | ((u64)a.w << 32);
+            h[2] = (u64)b.x | ((u64)b.y << 32); h[3] = (u64)b.z | ((u64)b.w << 32);
+            h[4] = (u64)c.x | ((u64)c.y << 32); h[5] = (u64)c.z | ((u64)c.w << 32);
+            h[6] = (u64)d.x | ((u64)d.y << 32); h[7] = (u64)d.z | ((u64)d.w << 32);
+        }
+        const u32 nl = n_kept - p0 < SK_E ? n_kept - p0 : SK_E;
+        live = (1u << nl) - 1u;
+        u32 heads = 0; // bit i: position p0 + i is the first of its sequence
+        if (B.in_lds) {
+            // the sequence that holds position p0: the last one whose run starts at or before it (empty runs skipped)
+            u32 lo = 0, hi = ns; // dseq[lo] <= p0 < dseq[hi]
+            while (hi - lo > 1) {
+                const u32 mid = (lo + hi) >> 1;
+                if ((u32)dseq[mid] <= p0) lo = mid; else hi = mid;
+            }
+            u32 s = lo, nxt = dseq[s + 1];
+#pragma unroll
+            for (int i = 0; i < SK_E; i++) {
+                const u32 p = p0 + i;
+                while (p >= nxt && s + 1 < ns) { s++; nxt = dseq[s + 1]; }
+                heads |= (p == (u32)dseq[s] ? 1u : 0u) << i;
+                srl[i >> 2] |= s << (8 * (i & 3));
+            }
+        } else {
+            heads = ((const u8 *)flagbits)[tid]; // (set below, before this phase, for tiles whose boundaries are not in LDS)
+        }
+        u64 prev = p0 ? tmp[p0 - 1] : 0;
+#pragma unroll
+        for (int i = 0; i < SK_E; i++) {
+            const bool r = h[i] != prev || ((heads >> i) & 1u);
+            rep |= (r ? 1u : 0u) << i;
+            prev = h[i];
+        }
+        rep = (rep | (p0 == 0 ? 1u : 0u)) & live;
+        dup = rep != live;
+    }
+    // The tile's postings (hash, sequence), partitioned on one hash digit, into the regions of that digit: digit-sort the
+    // representatives through tmp so that each digit leaves as one run.  Step 1 (here, from registers: the counting touches
+    // nothing but the digit bins, so the barrier that closes this phase closes it too): rank of every element inside its digit.
+    const bool posts = A.part_keys != nullptr && B.in_lds; // (uniform)
+    u32 rk[SK_E];
+    if (posts) {
 #pragma unroll
         for (int i = 0; i < SK_E; i++)
-            if (pa[i] & 1u) {
-                const u32 p = (pa[i] >> 1) & 0xfffu;
-                atomicOr(&flagbits[p >> 5], 1u << (p & 31));
-            }
+            if (rep & (1u << i)) rk[i] = atomicAdd(&bins[ks_join_prefix(h[i], A.part_K) & A.part_mask], 1u);
+    }
+    const bool any_dup = __syncthreads_or(dup); // (also: tmp is read, the LDS buffers may be reused; the digit bins are counted)
+
+    // Tiles without a repeat — for protein k-mers nearly all of them — are done: every kept hash is its own representative
+    // with abundance 1 and its distinct rank IS its sorted position.  The others: bit-prefix over the representative flags.
+    u32 ab[SK_E / 2]; // abundance of my representatives, 16 bits each (<= SK_TILE)
+#pragma unroll
+    for (int i = 0; i < SK_E / 2; i++) ab[i] = 0x00010001u;
+    if (any_dup) { // (uniform)
+        ((u8 *)flagbits)[tid] = (u8)rep; // bit p of the tile = position p holds a representative (threads behind n_kept: 0)
         __syncthreads();
         u32 v = tid < SK_NFLAG ? (u32)__popc(flagbits[tid]) : 0;
         u32 total;
         u32 ex = ks_block_excl_scan(v, scan_smem, &total);
         if (tid < SK_NFLAG) flagpre[tid] = ex;
         if (tid == 0) flagpre[SK_NFLAG] = total;
+        // run length of each representative = distance to the next one (or to the end of the kept hashes)
+        if (rep) {
+            u32 after = n_kept; // first representative at or behind position p0 + 8
+            for (u32 w = (p0 + SK_E) >> 5; w < SK_NFLAG; w++) {
+                u32 m = flagbits[w];
+                if (w == (p0 + SK_E) >> 5) m &= ~0u << ((p0 + SK_E) & 31u);
+                if (m) { after = w * 32u + (u32)__builtin_ctz(m); break; }
+            }
+#pragma unroll
+            for (int i = 0; i < SK_E; i++)
+                if (rep & (1u << i)) {
+                    const u32 later = rep >> (i + 1);
+                    const u32 len = later ? (u32)__builtin_ctz(later) + 1u : after - (p0 + i);
+                    ab[i >> 1] = (ab[i >> 1] & ~(0xffffu << ((i & 1) * 16))) | (len << ((i & 1) * 16));
+                }
+        }
         __syncthreads();
     }
     const u32 n_distinct = any_dup ? flagpre[SK_NFLAG] : n_kept;
@@ -687,54 +838,37 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         return x >= SK_TILE ? n_distinct : flagpre[x >> 5] + (u32)__popc(flagbits[x >> 5] & ((1u << (x & 31)) - 1u));
     };
     u16 *abund_s = (u16 *)cnt; // abundance staging reuses the bucket-start words once they are dead (<= 4096 fits 16 bits)
-    auto stage_reps = [&]() { // representatives -> LDS in distinct-rank order (tmp is free after phase 5)
+    auto stage_reps = [&]() { // (tiles with repeats) representatives -> LDS in distinct-rank order, over the sorted run
 #pragma unroll
-        for (int i = 0; i < SK_E; i++) {
-            if (pa[i] & 1u) {
-                const u32 d = drank((pa[i] >> 1) & 0xfffu);
+        for (int i = 0; i < SK_E; i++)
+            if (rep & (1u << i)) {
+                const u32 d = drank(p0 + i);
                 tmp[d] = h[i];
-                abund_s[d] = (u16)(pa[i] >> 16);
+                abund_s[d] = (u16)(ab[i >> 1] >> ((i & 1) * 16));
             }
-        }
     };
-
-    // The tile's postings (hash, sequence), partitioned on one hash digit, into the regions of that digit: digit-sort the
-    // representatives through tmp so that each digit leaves as one run.  LDS scratch: tmp, cnt (as 16-bit sequence codes),
-    // loff (as digit bins) — all free between the publication of the aggregate and stage_reps() when the boundaries are
-    // served from dseq.  The rank inside (tile, digit) goes into the dead bucket / slot bits of the element code.
-    __shared__ u32 gbase[256];
-    auto emit_postings = [&]() {
-        u32 *bins = loff;               // [256] count per digit, then exclusive start inside the tile
-        u16 *qrel = (u16 *)cnt;         // sequence (relative) of the element staged at tmp[pos]
-        __syncthreads();                // whoever read tmp / cnt / loff before is done
-        if (tid < 256) bins[tid] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < SK_E; i++)
-            if (pa[i] & 1u)
-                bo[i] = (bo[i] & 0xff000000u) | atomicAdd(&bins[ks_join_prefix(h[i], A.part_K) & A.part_mask], 1u);
-        __syncthreads();
-        {
-            const u32 c = tid < 256 ? bins[tid] : 0;
-            u32 total;
-            const u32 ex = ks_block_excl_scan(c, scan_smem, &total);
-            if (tid < 256) {
-                u32 off = 0;
-                if (c) {
-                    off = atomicAdd(&A.part_cursor[(tid << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u))], c);
-                    if ((u64)off + c > A.part_cap) atomicOr(&A.ticket[1], 2u); // region full: host falls back
-                }
-                gbase[tid] = off;
-                bins[tid] = ex;
-            }
+    // Postings, step 2: a slice of every digit's region for this tile (one device atomic per digit, requested here and
+    // awaited only when the slices are stored), digit starts inside the tile.
+    auto post_offsets = [&]() {
+        const u32 c = tid < 256 ? bins[tid] : 0;
+        u32 off = 0;
+        if (c) {
+            off = atomicAdd(&A.part_cursor[(tid << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u))], c);
+            if ((u64)off + c > A.part_cap) atomicOr(&A.ticket[1], 2u); // region full: host falls back
         }
-        __syncthreads();
+        const u32 ex = sk_block_excl_scan1(c, scan_smem);
+        if (tid < 256) { gbase[tid] = off; bins[tid] = ex; }
+    };
+    // Postings, step 3 (after a barrier that follows post_offsets and the last reader of tmp / cnt): digit order through tmp,
+    // sequence codes through the counter words, then one run per digit.
+    auto post_emit = [&]() {
+        u16 *qrel = (u16 *)cnt; // sequence (relative) of the element staged at tmp[pos]
 #pragma unroll
         for (int i = 0; i < SK_E; i++)
-            if (pa[i] & 1u) {
-                const u32 pos = bins[ks_join_prefix(h[i], A.part_K) & A.part_mask] + (bo[i] & 0xffffffu);
+            if (rep & (1u << i)) {
+                const u32 pos = bins[ks_join_prefix(h[i], A.part_K) & A.part_mask] + rk[i];
                 tmp[pos] = h[i];
-                qrel[pos] = (u16)SK_BO_S(bo[i]);
+                qrel[pos] = (u16)((srl[i >> 2] >> (8 * (i & 3))) & 0xffu);
             }
         __syncthreads();
         for (u32 i = tid; i < n_distinct; i += SK_THREADS) {
@@ -752,31 +886,26 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
 
     if (MODE == 1) {
         if (tid == 0) A.counts[s_first] = n_distinct;
-        __syncthreads();
         SK_STAMP_AT(6);
-        stage_reps();
-        __syncthreads();
+        if (any_dup) { // (the sorted run itself otherwise)
+            stage_reps();
+            __syncthreads();
+        }
         SK_STAMP_AT(7);
         // into the side buffer at the sequence's own offset; k_place_long moves it once its CSR slot is known
         const u64 r0 = A.offs[s_first];
         for (u32 d = tid; d < n_distinct; d += SK_THREADS) {
             A.out_hash[r0 + d] = tmp[d];
-            A.out_abund[r0 + d] = abund_s[d];
+            A.out_abund[r0 + d] = any_dup ? (u32)abund_s[d] : 1u;
+        }
+        if (posts) { // a medium tile emits its own postings
+            post_offsets();
+            __syncthreads();
+            post_emit();
         }
     } else {
-        // distinct rank at every sequence start; a deferred (medium / long) sequence that starts inside this tile (at
-        // most one: the last) brings its unique count from the earlier launches into the aggregate
-        for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
-            const u32 ls = B.at(s), le = B.at(s + 1);
-            // (first bucket of the sequence: its local start, or the compacted base the bucket table holds)
-            const u32 d0 = drank(bstart(CMP ? ((const uint2 *)res_w)[s - s_first].x : ls));
-            if (B.in_lds) dseq[s - s_first] = (u16)d0;
-            if (le > A.le_cap || le - ls > A.max_len_tile) {
-                const u32 e = atomicAdd(&ext_n, 1u);
-                if (e < 4) { ext_seq[e] = s; ext_cnt[e] = A.counts[s]; ext_d[e] = d0; }
-            }
-        }
-        __syncthreads();
+        // a deferred (medium / long) sequence that starts inside this tile (noted in phase 4) brings its unique count from
+        // the earlier launches into the aggregate
         const u32 ne = ext_n < 4 ? ext_n : 4;
         u64 agg = n_distinct;
         for (u32 e = 0; e < ne; e++) agg += ext_cnt[e];
@@ -784,17 +913,31 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         if (tid == 0)
             __hip_atomic_store(&A.tile_status[tile], (tile == 0 ? SK_FLAG_PRE : SK_FLAG_AGG) | agg, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        // The look-back below waits for the predecessors' aggregates, and a predecessor publishes only after its own rank /
-        // unique phases: 11 % of a workgroup's life was spent in that wait (per-phase clocks, profiles/).  The postings do
-        // not need the tile's CSR base, so they are emitted HERE, between publication and look-back: by the time wave 0 looks
-        // back, its predecessors have long published.
-        if (A.part_keys && B.in_lds) {
-            emit_postings();
-            __syncthreads(); // tmp / cnt are staged over next
-        }
-        if (B.in_lds) { // bucket starts are dead (dseq holds what the CSR needs): stage now, look back after
-            stage_reps();
+        // The look-back below waits for the predecessors' aggregates, and a predecessor publishes only after its own sort /
+        // unique phases.  What does not need the tile's CSR base goes HERE, between publication and look-back: the posting
+        // slices, the distinct rank of every sequence start, the staging of a tile with repeats.
+        if (posts) post_offsets();
+        if (B.in_lds && (any_dup || ne)) // distinct rank at every sequence start (tiles without repeats: dseq as it stands)
+            for (u32 i = tid; i < ns; i += SK_THREADS) {
+                const u32 d0 = drank(dseq[i]);
+                for (u32 e = 0; e < ne; e++)
+                    if (ext_seq[e] == s_first + i) ext_d[e] = d0;
+                if (any_dup) dseq[i] = (u16)d0; // (own entry; the walks of phase 6 are done)
+            }
+        if (!B.in_lds && tid < ne) ext_d[tid] = drank(bstart(B.at(ext_seq[tid])));
+        if (posts) { // the postings leave first: their digit order goes through tmp, the sorted run is staged again behind them
             __syncthreads();
+            post_emit();
+            __syncthreads();
+        }
+        if (B.in_lds) { // bucket starts are dead (dseq holds what the CSR needs)
+            if (any_dup) stage_reps();
+            else if (posts && p0 < n_kept) { // the sorted run as it was: 8 consecutive positions per thread
+                *(uint4 *)&tmp[p0] = make_uint4((u32)h[0], (u32)(h[0] >> 32), (u32)h[1], (u32)(h[1] >> 32));
+                *(uint4 *)&tmp[p0 + 2] = make_uint4((u32)h[2], (u32)(h[2] >> 32), (u32)h[3], (u32)(h[3] >> 32));
+                *(uint4 *)&tmp[p0 + 4] = make_uint4((u32)h[4], (u32)(h[4] >> 32), (u32)h[5], (u32)(h[5] >> 32));
+                *(uint4 *)&tmp[p0 + 6] = make_uint4((u32)h[6], (u32)(h[6] >> 32), (u32)h[7], (u32)(h[7] >> 32));
+            }
         }
         SK_STAMP_AT(6);
         // ---- step 2: wave 0 sums the predecessors' aggregates back to the nearest inclusive prefix
@@ -815,7 +958,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                             v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                     }
-                    if ((v >> 62) == 0) { A.ticket[1] = 1; v = SK_FLAG_PRE; } // spin bound expired: flag the error, do not hang
+                    if ((v >> 62) == 0) { atomicOr(&A.ticket[1], 1u); v = SK_FLAG_PRE; } // spin bound expired: flag the error, do not hang
                     const u64 is_pre = __ballot((v >> 62) == 2);
                     // lanes at or before the first inclusive prefix contribute
                     const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
@@ -829,7 +972,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             }
             if (tid == 0) base_s = excl;
         }
-        __syncthreads();
+        __syncthreads(); // (base_s; and everything placed between publication and look-back)
         const u64 base = base_s;
         // final CSR offsets of every sequence that starts in this tile
         for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
@@ -838,7 +981,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             A.csr[s] = pos;
         }
         if (s_end == A.n_seqs && tid == 0) { A.csr[A.n_seqs] = base + agg; *A.total_out = base + agg; }
-        if (!B.in_lds) { // rare: more sequences than the LDS table holds, so the starts were needed until here
+        if (!B.in_lds && any_dup) { // rare: more sequences than the LDS table holds, so the starts were needed until here
             __syncthreads();
             stage_reps();
             __syncthreads();
@@ -851,17 +994,12 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             for (u32 e = 0; e < ne; e++) pos += ext_d[e] <= d ? ext_cnt[e] : 0;
             if (pos < A.out_cap) { // (capacity-bounded output: the host sees the true total in csr[n_seqs] and repeats larger)
                 A.out_hash[pos] = tmp[d];
-                A.out_abund[pos] = abund_s[d];
+                A.out_abund[pos] = any_dup ? (u32)abund_s[d] : 1u;
             }
         }
     }
-    // ---- phase 9 (optional): the tile's postings (medium tiles; shared tiles emitted theirs before the look-back)
-    if (A.part_keys) {
-        if (!B.in_lds) { // sequence ids do not fit the element code: let the host repartition this batch
-            if (tid == 0) atomicOr(&A.ticket[1], 2u);
-        } else if (MODE == 1) {
-            emit_postings();
-        }
+    if (A.part_keys && !B.in_lds) { // sequence ids do not fit the element code: let the host repartition this batch
+        if (tid == 0) atomicOr(&A.ticket[1], 2u);
     }
     SK_STAMP_AT(8);
 }
@@ -869,7 +1007,8 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
 // MODE 0: one shared tile per workgroup, ids in dispatch order (the look-back relies on it).  MODE 1: the medium
 // sequences — their number is only known on the device (*A.n_list), so a fixed grid strides over the list.
 template <int MODE, int CMP>
-__global__ __launch_bounds__(SK_THREADS, SK_MINW) void k_sketch_tiles(sk_args A) {
+// (medium tiles — a side launch of few workgroups — may take more registers instead of spilling: 2 workgroups per CU)
+__global__ __launch_bounds__(SK_THREADS, MODE == 1 ? 4 : SK_MINW) void k_sketch_tiles(sk_args A) {
     if (MODE == 1) {
         const u32 n = *A.n_list < A.n_list_cap ? *A.n_list : A.n_list_cap;
         for (u32 t = blockIdx.x; t < n; t += gridDim.x) {

@@ -94,13 +94,16 @@ def main():
         for n, a in (("t_res", t_res), ("t_off", t_off), ("q_res", q_res), ("q_off", q_off)):
             np.save(f"{cache}.{n}.npy", a)
     for v in args.variants:
-        defs = [] if v == "base" else v.split(",")
-        so = f"/tmp/libks_{abs(hash(v)) % 10**8}.so"
-        try:
-            ks_build.build(force=True, defs=defs, out=so)
-        except subprocess.CalledProcessError as e:
-            print(json.dumps({"variant": v, "error": "build failed"}))
-            continue
+        if v.startswith("lib="):  # a prebuilt library (e.g. an earlier commit's, built into kmerseek_amd/variants/)
+            so = os.path.abspath(v[4:])
+        else:
+            defs = [] if v == "base" else v.split(",")
+            so = f"/tmp/libks_{abs(hash(v)) % 10**8}.so"
+            try:
+                ks_build.build(force=True, defs=defs, out=so)
+            except subprocess.CalledProcessError as e:
+                print(json.dumps({"variant": v, "error": "build failed"}))
+                continue
         env = dict(os.environ, KMERSEEK_AMD_LIB=so)
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--variant", v, "--cache", cache,
                "--ksize", str(args.ksize), "--scaled", str(args.scaled), "--moltype", args.moltype,
