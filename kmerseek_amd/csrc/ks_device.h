@@ -78,15 +78,20 @@ KS_DEV bool ks_spin_expired(long long t0, u32 &polls) {
 }
 
 // ---- wave / block exclusive scans (u32) ----
+// Inclusive scan over the 64 lanes of a wave with DPP moves only (no LDS crossbar round trips: __shfl_up lowers to
+// ds_bpermute_b32): four row_shr steps scan each row of 16, row_bcast:15 carries row 0 -> 1 and row 2 -> 3, row_bcast:31
+// carries the first half into the second.  Lanes without a source add 0.
 KS_DEV u32 ks_wave_incl_scan(u32 v) {
-    const u32 lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 t = __shfl_up(v, d, 64);
-        if (lane >= (u32)d) v += t;
-    }
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
     return v;
 }
+// value of the lane below (lane 0: 0)
+KS_DEV u32 ks_lane_below(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); } // wave_shr:1
 
 // Block-wide exclusive scan; `smem` must hold (blockDim.x/64 + 1) u32.  Returns the exclusive
 // prefix of v; *total receives the block sum.  Contains three __syncthreads().

@@ -25,7 +25,9 @@
 //     one workgroup per sequence.
 #include "ks_device.h"
 
+#ifndef SK_THREADS
 #define SK_THREADS 512
+#endif
 #define SK_E 8
 #define SK_TILE (SK_THREADS * SK_E) // 4096 LDS positions
 #define SK_MED_MAX (SK_TILE - 16)   // longest sequence that still fits one tile on its own ("medium")
@@ -41,6 +43,9 @@ static const u32 sk_r_cand_host[SK_NR] = {2544, 2800, 3056, 3312, 3568, 3824, 39
 #define SK_MINW 6                   // waves per SIMD to compile for: 3 workgroups of 8 waves per CU
 #endif
 #define SK_NFLAG (SK_TILE / 32)
+#ifndef SK_LB_WAVES
+#define SK_LB_WAVES 1 // waves of a workgroup that look back (64 predecessors each)
+#endif
 #define SK_C3MAX 32u                // a bucket of more hashes than this is put in order by the whole workgroup
 #define SK_QB_CAP 128u              // >= SK_TILE / (SK_C3MAX + 1): list of those buckets (16-bit entries)
 
@@ -75,6 +80,7 @@ struct sk_args {
     u64 max_hash;
     u32 sfix;     // floor(2^48 / ((max_hash >> 32) + 1)): bucket multiplier = (n_windows * sfix) >> 16
     const u8 *lut; // 256-byte encode table for this moltype
+    u32 upper_only; // the table only upper-cases (moltype protein): applied arithmetically
     u32 R;         // tile stride in residues (see sk_r_cand); 0 = packed tiles (tile_g0 gives each tile's first residue)
     const u64 *tile_g0; // packed tiles: 16-byte aligned residue offset the tile's LDS window starts at
     u32 span;      // residues a shared tile covers from tile * R: SK_TILE, or more for the compacting variant (scaled > 1)
@@ -155,12 +161,7 @@ KS_DEV u32 sk_div(u32 x, u32 d, u32 rcp) { return d == 1 ? x : __umulhi(x, rcp);
 KS_DEV u32 sk_block_excl_scan2(u32 a, u32 b, u32 *smem, u32 *total_a, u32 *excl_b) {
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr u32 NW = SK_THREADS / 64;
-    u32 ia = a, ib = b;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
-        if (lane >= (u32)d) { ia += ta; ib += tb; }
-    }
+    const u32 ia = ks_wave_incl_scan(a), ib = ks_wave_incl_scan(b);
     if (lane == 63) { smem[wave] = ia; smem[NW + 1 + wave] = ib; }
     __syncthreads();
     u32 base_a = 0, base_b = 0, tot_a = 0, tot_b = 0;
@@ -372,7 +373,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     static_assert(!(CMP && MODE), "the compacting variant is for shared tiles");
     __shared__ __attribute__((aligned(16))) u64 res_w[(SK_TILE + SK_PAD) / 8];
     __shared__ __attribute__((aligned(16))) u32 cnt[SK_TILE / 2 + 4]; // bucket counts, then starts: 16 bits each
-    __shared__ u16 dseq[SK_SEQ_CAP + 2];                               // distinct rank at each sequence start
+    __shared__ __attribute__((aligned(8))) u16 dseq[SK_SEQ_CAP + 2];                               // distinct rank at each sequence start
     __shared__ __attribute__((aligned(16))) u64 tmp[SK_TILE];
     __shared__ u32 flagbits[SK_NFLAG];
     __shared__ u32 flagpre[SK_NFLAG + 1];
@@ -391,8 +392,10 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     // ---- phase 0: tile -> sequence range (planned ahead), zero LDS state, stage LUT + sequence boundaries
     __shared__ u32 tile_s;
     __shared__ u32 ext_n;
+    __shared__ u32 ndup_s; // repeats counted in phase 5
     __shared__ u32 ext_seq[4], ext_cnt[4], ext_d[4];
-    __shared__ unsigned long long base_s;
+    __shared__ unsigned long long lb_sum[SK_THREADS / 64]; // look-back: per wave, aggregates up to its first inclusive prefix
+    __shared__ u32 lb_pre[SK_THREADS / 64];                // ... and whether it saw one
     u32 tile = tile_in;
     constexpr u32 NCH = (SK_TILE + SK_PAD) / 16; // 16-byte chunks of a staged tile
     static_assert(NCH <= SK_THREADS, "one staging chunk per thread");
@@ -410,7 +413,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
     if (tid < SK_NFLAG) flagbits[tid] = 0;
     __shared__ u32 n_list_s; // CMP: kept windows appended to the list so far
-    if (tid == 0) { ext_n = 0; n_list_s = 0; }
+    if (tid == 0) { ext_n = 0; n_list_s = 0; ndup_s = 0; }
     if (MODE == 0 && A.use_ticket) { // (uniform)
         // tiles are handed out in ticket order, so every predecessor a look-back waits for is already running
         if (tid == 0) tile_s = ticket_v;
@@ -426,10 +429,19 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     auto stage_chunk = [&](uint4 v) { // through the encode LUT into the tile's residue buffer, 16 B per lane
         const u32 in[4] = {v.x, v.y, v.z, v.w};
         u32 o[4];
+        if (A.upper_only) { // (uniform) moltype protein: the table only upper-cases — four bytes at a time, no table, no barrier for it
 #pragma unroll
-        for (int d = 0; d < 4; d++)
-            o[d] = (u32)lut_s[in[d] & 255u] | ((u32)lut_s[(in[d] >> 8) & 255u] << 8) |
-                   ((u32)lut_s[(in[d] >> 16) & 255u] << 16) | ((u32)lut_s[in[d] >> 24] << 24);
+            for (int d = 0; d < 4; d++) {
+                const u32 y = in[d] & 0x7f7f7f7fu; // (no carry between bytes: 0x7f + 0x1f < 0x100)
+                const u32 lower = (y + 0x1f1f1f1fu) & ~(y + 0x05050505u) & ~in[d] & 0x80808080u; // bytes in 'a' .. 'z'
+                o[d] = in[d] ^ (lower >> 2);
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+                o[d] = (u32)lut_s[in[d] & 255u] | ((u32)lut_s[(in[d] >> 8) & 255u] << 8) |
+                       ((u32)lut_s[(in[d] >> 16) & 255u] << 16) | ((u32)lut_s[in[d] >> 24] << 24);
+        }
         *(uint4 *)(res_b + (size_t)tid * 16) = make_uint4(o[0], o[1], o[2], o[3]);
     };
     uint4 rv = make_uint4(0, 0, 0, 0);
@@ -467,7 +479,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         }
         __syncthreads(); // lut_s
     }
-    if (MODE == 0) __syncthreads(); // the LUT and the zeroed LDS state (the tile's global loads are in flight)
+    if (MODE == 0 && !A.upper_only) __syncthreads(); // the LUT (the tile's global loads are in flight; the zeroed LDS state is first touched behind the next barrier)
     if (tid < NCH) stage_chunk(rv);
     __syncthreads();
 
@@ -624,11 +636,12 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         }
         *(uint4 *)&cnt[q0 >> 1] = make_uint4(o[0], o[1], o[2], o[3]);
         if (tid == SK_THREADS - 1) cnt[SK_TILE / 2] = total | (total << 16);
-        // list entries = bucket numbers
+        // list entries: the first position of a pair; bucket numbers otherwise
         while (m2) {
             const u32 bit = (u32)__builtin_ctz(m2);
             m2 &= m2 - 1u;
-            if (i2 < q2cap) q2[i2] = (u16)(q0 + 2u * (bit & 15u) + (bit >> 4)); else ovf |= 1u << bit;
+            const u32 j = bit & 15u, wsel = j == 0 ? o[0] : (j == 1 ? o[1] : (j == 2 ? o[2] : o[3]));
+            if (i2 < q2cap) q2[i2] = (u16)((wsel >> (bit & 16u)) & 0xffffu); else ovf |= 1u << bit; // the pair's first position
             i2++;
         }
         while (m3) {
@@ -675,13 +688,16 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     SK_STAMP_AT(4);
     // ---- phase 5: put the listed buckets in order, in place.  tmp then holds the tile's kept hashes sorted by
     // (sequence, hash): equal hashes of a sequence are neighbours.
+    // Equal hashes of a sequence share a bucket, so whoever orders a bucket also sees every repeat: their count makes the
+    // tile's number of DISTINCT hashes known here, before anything is read back.
+    u32 nd = 0; // repeats seen by me
     auto sort_small = [&](u32 sb, u32 c) { // insertion sort of tmp[sb, sb + c)
         for (u32 a = 1; a < c; a++) {
             const u64 x = tmp[sb + a];
             u32 j = a;
             while (j > 0) {
                 const u64 y = tmp[sb + j - 1];
-                if (y <= x) break;
+                if (y <= x) { nd += y == x ? 1u : 0u; break; }
                 tmp[sb + j] = y;
                 j--;
             }
@@ -694,9 +710,10 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         const u32 n3 = ((qc >> 12) & 0xfffu) < q3cap ? ((qc >> 12) & 0xfffu) : q3cap;
         const u32 nb = qc >> 24;
         for (u32 e = tid; e < n2; e += SK_THREADS) {
-            const u32 sb = bstart(q2[e]);
+            const u32 sb = q2[e];
             const u64 x = tmp[sb], y = tmp[sb + 1];
             if (x > y) { tmp[sb] = y; tmp[sb + 1] = x; }
+            nd += x == y ? 1u : 0u;
         }
         // (from the last thread down: the waves a second round of pairs keeps busy are the first ones)
         for (u32 e = SK_THREADS - 1u - tid; e < n3; e += SK_THREADS) {
@@ -713,42 +730,62 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                   // all threads rank one bucket's elements by counting (equal hashes keep their order), then move them
             for (u32 e = 0; e < nb; e++) {
                 const u32 b = qb[e], sb = bstart(b), c = bstart(b + 1) - sb;
-                __syncthreads();
                 u64 xs[SK_E];
-                u32 rk[SK_E];
+                u32 rkb[SK_E];
 #pragma unroll
                 for (int i = 0; i < SK_E; i++) {
                     const u32 j = (u32)i * SK_THREADS + tid; // c <= SK_TILE = SK_E * SK_THREADS
-                    rk[i] = 0xffffffffu;
+                    rkb[i] = 0xffffffffu;
                     if (j < c) {
                         const u64 x = tmp[sb + j];
-                        u32 r = 0;
+                        u32 r = 0, seen = 0;
                         for (u32 m = 0; m < c; m++) {
                             const u64 y = tmp[sb + m];
-                            r += (y < x) | ((y == x) & (m < j));
+                            const u32 eqb = (y == x) & (m < j);
+                            r += (y < x) | eqb;
+                            seen |= eqb;
                         }
-                        xs[i] = x; rk[i] = r;
+                        xs[i] = x; rkb[i] = r;
+                        nd += seen;
                     }
                 }
                 __syncthreads();
 #pragma unroll
                 for (int i = 0; i < SK_E; i++)
-                    if (rk[i] != 0xffffffffu) tmp[sb + rk[i]] = xs[i];
+                    if (rkb[i] != 0xffffffffu) tmp[sb + rkb[i]] = xs[i];
             }
         }
     }
+    if (nd) atomicAdd(&ndup_s, nd);
     __syncthreads();
+    const u32 n_rep = ndup_s;          // hashes of the tile that repeat an earlier one of their sequence
+    const bool any_dup = n_rep != 0;   // (uniform)
+    const u32 n_distinct = n_kept - n_rep;
+    const bool posts = A.part_keys != nullptr && B.in_lds; // (uniform)
+    // ---- decoupled look-back, step 1 (MODE 0): publish this tile's aggregate as early as possible — a successor's look-back
+    // waits for it (0.5 ms of a 2.5 ms launch went to that wait when the aggregate was only published after phase 6).
+    // A deferred (medium / long) sequence that starts inside this tile (noted in phase 4) brings its unique count from the
+    // earlier launches into the aggregate.
+    const u32 ne = MODE == 0 ? (ext_n < 4 ? ext_n : 4) : 0;
+    u64 agg = n_distinct;
+    for (u32 e = 0; e < ne; e++) agg += ext_cnt[e];
+    if (MODE == 0 && tid == 0)
+        __hip_atomic_store(&A.tile_status[tile], (tile == 0 ? SK_FLAG_PRE : SK_FLAG_AGG) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     SK_STAMP_AT(5);
-    // ---- phase 6: every thread takes 8 consecutive SORTED positions back into registers (the LDS buffers are reused below).
-    // A hash that equals its left neighbour inside the same sequence is a repeat: the first of a run is the representative,
-    // the run's length its abundance.
+    // ---- phase 6 (tiles with repeats, tiles that emit postings): every thread takes 8 consecutive SORTED positions back into
+    // registers (the LDS buffers are reused below).  A hash that equals its left neighbour inside the same sequence is a
+    // repeat: the first of a run is the representative, the run's length its abundance.  A tile without repeats that emits
+    // no postings — the index side, nearly always — skips all of this: its sorted run in tmp is what leaves.
     const u32 p0 = tid * SK_E;
     u32 rep = 0;          // bit i: position p0 + i holds a representative
-    u32 live = 0;         // bit i: position p0 + i < n_kept
     u32 srl[2] = {0, 0};  // sequence (relative to the tile's first) of each position, 8 bits each (tiles of <= SK_SEQ_CAP sequences)
-    bool dup = false;
-    if (p0 < n_kept) {
+    u32 rk[SK_E];         // postings: rank of my element inside (tile, digit)
+    u32 ab[SK_E / 2];     // abundance of my representatives, 16 bits each (<= SK_TILE)
+#pragma unroll
+    for (int i = 0; i < SK_E / 2; i++) ab[i] = 0x00010001u;
+    if (any_dup || posts) { // (uniform)
+    if ((tid & ~63u) * SK_E < n_kept) { // (whole waves: the sequence lookup below works with all lanes of a wave)
         {
             const uint4 a = *(const uint4 *)&tmp[p0], b = *(const uint4 *)&tmp[p0 + 2], c = *(const uint4 *)&tmp[p0 + 4],
                         d = *(const uint4 *)&tmp[p0 + 6];
@@ -757,54 +794,97 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             h[4] = (u64)c.x | ((u64)c.y << 32); h[5] = (u64)c.z | ((u64)c.w << 32);
             h[6] = (u64)d.x | ((u64)d.y << 32); h[7] = (u64)d.z | ((u64)d.w << 32);
         }
-        const u32 nl = n_kept - p0 < SK_E ? n_kept - p0 : SK_E;
-        live = (1u << nl) - 1u;
+        const u32 nl = p0 >= n_kept ? 0u : (n_kept - p0 < SK_E ? n_kept - p0 : SK_E);
+        const u32 live = (1u << nl) - 1u; // bit i: position p0 + i < n_kept
         u32 heads = 0; // bit i: position p0 + i is the first of its sequence
         if (B.in_lds) {
-            // the sequence that holds position p0: the last one whose run starts at or before it (empty runs skipped)
-            u32 lo = 0, hi = ns; // dseq[lo] <= p0 < dseq[hi]
-            while (hi - lo > 1) {
-                const u32 mid = (lo + hi) >> 1;
-                if ((u32)dseq[mid] <= p0) lo = mid; else hi = mid;
-            }
-            u32 s = lo, nxt = dseq[s + 1];
+            // Which sequence holds each of my positions: sequence s owns sorted positions [dseq[s], dseq[s + 1]) (empty runs
+            // included), so the sequence of position p is the number of boundaries dseq[1 .. ns] at or before p.  Per WAVE
+            // (512 consecutive positions from pw): the boundaries before pw are counted by all lanes together (4 table
+            // entries per lane, one ballot each); the next 8 boundaries are read once (the same address in every lane)
+            // and kept in registers, and a boundary at offset e from my first position adds 1 to the nibble of every position
+            // from e on: 0x11111111 << 4e.  No chain of dependent LDS reads.  A wave whose 512 positions hold more than 8
+            // boundaries (many tiny sequences) walks the table instead.
+            const u32 lane = tid & 63u, pw = (tid & ~63u) * SK_E;
+            u32 nb4 = 0;
+            {
+                const uint2 dd = *(const uint2 *)&dseq[4u * lane];
+                const u32 dv[4] = {dd.x & 0xffffu, dd.x >> 16, dd.y & 0xffffu, dd.y >> 16};
 #pragma unroll
-            for (int i = 0; i < SK_E; i++) {
-                const u32 p = p0 + i;
-                while (p >= nxt && s + 1 < ns) { s++; nxt = dseq[s + 1]; }
-                heads |= (p == (u32)dseq[s] ? 1u : 0u) << i;
-                srl[i >> 2] |= s << (8 * (i & 3));
+                for (int i = 0; i < 4; i++) {
+                    const u32 j = 4u * lane + (u32)i;
+                    nb4 += (u32)__popcll(__ballot(j >= 1u && j <= ns && dv[i] < pw));
+                }
+            }
+            const u32 Bw = __builtin_amdgcn_readfirstlane(nb4); // boundaries before pw = the sequence that holds position pw - 1
+            u32 acc = 0;
+            u32 dlast = 0xffffu;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const u32 j = Bw + 1u + (u32)k;
+                const u32 dk = j <= ns ? (u32)dseq[j] : 0xffffu;
+                const i32 e = (i32)dk - (i32)p0;
+                const u32 ec = (u32)(e < 0 ? 0 : (e > 8 ? 8 : e));
+                acc += (u32)(0x11111111ULL << (4u * ec));
+                dlast = dk;
+            }
+            if (dlast >= pw + 64u * SK_E) { // (uniform) the common case: no further boundary inside this wave's positions
+                const u32 below = ks_lane_below(acc >> 28); // boundaries (from pw) at or before the position left of mine
+                u32 x = acc ^ ((acc << 4) | below);         // nibble i != 0: position p0 + i starts a sequence
+                x |= x >> 1; x |= x >> 2; x &= 0x11111111u;
+                x = (x | (x >> 3)) & 0x03030303u;
+                x = (x | (x >> 6)) & 0x000f000fu;
+                heads = (x | (x >> 12)) & 0xffu;
+                u32 lo = acc & 0xffffu, hi = acc >> 16;
+                lo = (lo | (lo << 8)) & 0x00ff00ffu; lo = (lo | (lo << 4)) & 0x0f0f0f0fu;
+                hi = (hi | (hi << 8)) & 0x00ff00ffu; hi = (hi | (hi << 4)) & 0x0f0f0f0fu;
+                srl[0] = lo + Bw * 0x01010101u;
+                srl[1] = hi + Bw * 0x01010101u;
+            } else {
+                // the sequence that holds position p0: the last one whose run starts at or before it (empty runs skipped)
+                u32 lo = 0, hi = ns; // dseq[lo] <= p0 < dseq[hi]
+                while (hi - lo > 1) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if ((u32)dseq[mid] <= p0) lo = mid; else hi = mid;
+                }
+                u32 s = lo, nxt = dseq[s + 1];
+#pragma unroll
+                for (int i = 0; i < SK_E; i++) {
+                    const u32 p = p0 + i;
+                    while (p >= nxt && s + 1 < ns) { s++; nxt = dseq[s + 1]; }
+                    heads |= (p == (u32)dseq[s] ? 1u : 0u) << i;
+                    srl[i >> 2] |= s << (8 * (i & 3));
+                }
             }
         } else {
-            heads = ((const u8 *)flagbits)[tid]; // (set below, before this phase, for tiles whose boundaries are not in LDS)
+            heads = ((const u8 *)flagbits)[tid]; // (set in phase 4 for tiles whose boundaries are not in LDS)
         }
-        u64 prev = p0 ? tmp[p0 - 1] : 0;
+        rep = live;
+        if (any_dup) {
+            u64 prev = p0 ? tmp[p0 - 1] : 0;
+            rep = 0;
 #pragma unroll
-        for (int i = 0; i < SK_E; i++) {
-            const bool r = h[i] != prev || ((heads >> i) & 1u);
-            rep |= (r ? 1u : 0u) << i;
-            prev = h[i];
+            for (int i = 0; i < SK_E; i++) {
+                const bool r = h[i] != prev || ((heads >> i) & 1u);
+                rep |= (r ? 1u : 0u) << i;
+                prev = h[i];
+            }
+            rep = (rep | (p0 == 0 ? 1u : 0u)) & live;
         }
-        rep = (rep | (p0 == 0 ? 1u : 0u)) & live;
-        dup = rep != live;
     }
     // The tile's postings (hash, sequence), partitioned on one hash digit, into the regions of that digit: digit-sort the
     // representatives through tmp so that each digit leaves as one run.  Step 1 (here, from registers: the counting touches
     // nothing but the digit bins, so the barrier that closes this phase closes it too): rank of every element inside its digit.
-    const bool posts = A.part_keys != nullptr && B.in_lds; // (uniform)
-    u32 rk[SK_E];
     if (posts) {
 #pragma unroll
         for (int i = 0; i < SK_E; i++)
             if (rep & (1u << i)) rk[i] = atomicAdd(&bins[ks_join_prefix(h[i], A.part_K) & A.part_mask], 1u);
     }
-    const bool any_dup = __syncthreads_or(dup); // (also: tmp is read, the LDS buffers may be reused; the digit bins are counted)
+    __syncthreads(); // (tmp is read, the LDS buffers may be reused; the digit bins are counted)
+    }
 
     // Tiles without a repeat — for protein k-mers nearly all of them — are done: every kept hash is its own representative
     // with abundance 1 and its distinct rank IS its sorted position.  The others: bit-prefix over the representative flags.
-    u32 ab[SK_E / 2]; // abundance of my representatives, 16 bits each (<= SK_TILE)
-#pragma unroll
-    for (int i = 0; i < SK_E / 2; i++) ab[i] = 0x00010001u;
     if (any_dup) { // (uniform)
         ((u8 *)flagbits)[tid] = (u8)rep; // bit p of the tile = position p holds a representative (threads behind n_kept: 0)
         __syncthreads();
@@ -831,7 +911,6 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         }
         __syncthreads();
     }
-    const u32 n_distinct = any_dup ? flagpre[SK_NFLAG] : n_kept;
 
     auto drank = [&](u32 x) -> u32 { // representatives among sorted positions < x
         if (!any_dup) return x < n_kept ? x : n_kept;
@@ -904,15 +983,6 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             post_emit();
         }
     } else {
-        // a deferred (medium / long) sequence that starts inside this tile (noted in phase 4) brings its unique count from
-        // the earlier launches into the aggregate
-        const u32 ne = ext_n < 4 ? ext_n : 4;
-        u64 agg = n_distinct;
-        for (u32 e = 0; e < ne; e++) agg += ext_cnt[e];
-        // ---- decoupled look-back, step 1: publish this tile's aggregate as early as possible
-        if (tid == 0)
-            __hip_atomic_store(&A.tile_status[tile], (tile == 0 ? SK_FLAG_PRE : SK_FLAG_AGG) | agg, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
         // The look-back below waits for the predecessors' aggregates, and a predecessor publishes only after its own sort /
         // unique phases.  What does not need the tile's CSR base goes HERE, between publication and look-back: the posting
         // slices, the distinct rank of every sequence start, the staging of a tile with repeats.
@@ -940,40 +1010,54 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             }
         }
         SK_STAMP_AT(6);
-        // ---- step 2: wave 0 sums the predecessors' aggregates back to the nearest inclusive prefix
-        if (tid < 64) {
-            u64 excl = 0;
-            if (tile > 0) {
-                i64 idx = (i64)tile - 1;
-                bool done = false;
-                u32 spins = 0;
-                const long long spin_t0 = wall_clock64();
-                while (!done) {
-                    const i64 mine = idx - (i64)tid;
-                    u64 v = SK_FLAG_PRE; // before tile 0: inclusive prefix 0
-                    if (mine >= 0) {
+        // ---- step 2: the predecessors' aggregates are summed back to the nearest inclusive prefix, SK_THREADS predecessors at a
+        // time: wave w looks at the 64 tiles behind tile - 64 w.  (One wave looking back 64 at a time cost 0.5 ms of a 2.5 ms
+        // launch: with ~770 tiles in flight, started ~35 ns apart, the nearest tile that has finished ITS look-back is
+        // (look-back time / 35 ns) tiles away, so every round trip of the walk lengthens the next tile's walk — with tiles
+        // 3/4 or half the size, 1000+ in flight, that feedback made the kernel 1.4x / 1.8x slower.)
+        u64 excl = 0;
+#ifdef SK_NO_LOOKBACK // diagnostic build only: wrong CSR, the kernel's time without the wait for the predecessors
+        excl = (u64)tile * 3600u;
+        if (false) {
+#else
+        if (tile > 0) { // (uniform)
+#endif
+            const u32 lane = tid & 63u, wave = tid >> 6;
+            i64 idx = (i64)tile - 1;
+            u32 spins = 0;
+            const long long spin_t0 = wall_clock64();
+            for (;;) {
+                const i64 mine = idx - (i64)tid;
+                u64 v = SK_FLAG_PRE; // before tile 0: inclusive prefix 0
+                if (mine >= 0 && wave < SK_LB_WAVES) {
+                    v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((v >> 62) == 0 && !ks_spin_expired(spin_t0, spins)) {
+                        __builtin_amdgcn_s_sleep(1);
                         v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        while ((v >> 62) == 0 && !ks_spin_expired(spin_t0, spins)) {
-                            __builtin_amdgcn_s_sleep(1);
-                            v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
                     }
-                    if ((v >> 62) == 0) { atomicOr(&A.ticket[1], 1u); v = SK_FLAG_PRE; } // spin bound expired: flag the error, do not hang
-                    const u64 is_pre = __ballot((v >> 62) == 2);
-                    // lanes at or before the first inclusive prefix contribute
-                    const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
-                    u64 contrib = tid <= first ? (v & SK_VAL_MASK) : 0;
-                    for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
-                    excl += contrib;
-                    if (is_pre) done = true; else idx -= 64;
                 }
-                if (tid == 0)
-                    __hip_atomic_store(&A.tile_status[tile], SK_FLAG_PRE | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 62) == 0) { atomicOr(&A.ticket[1], 1u); v = SK_FLAG_PRE; } // spin bound expired: flag the error, do not hang
+                const u64 is_pre = __ballot((v >> 62) == 2);
+                // lanes at or before the wave's first inclusive prefix contribute
+                const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
+                u64 contrib = lane <= first ? (v & SK_VAL_MASK) : 0;
+                for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+                if (lane == 0) { lb_sum[wave] = contrib; lb_pre[wave] = is_pre ? 1u : 0u; }
+                __syncthreads(); // (the first one also orders everything placed between publication and look-back)
+                bool found = false;
+#pragma unroll
+                for (u32 w = 0; w < SK_LB_WAVES; w++)
+                    if (!found) { excl += lb_sum[w]; found = lb_pre[w] != 0; }
+                if (found) break;
+                idx -= 64 * SK_LB_WAVES;
+                __syncthreads(); // (lb_sum / lb_pre are written again)
             }
-            if (tid == 0) base_s = excl;
+            if (tid == 0)
+                __hip_atomic_store(&A.tile_status[tile], SK_FLAG_PRE | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __syncthreads();
         }
-        __syncthreads(); // (base_s; and everything placed between publication and look-back)
-        const u64 base = base_s;
+        const u64 base = excl;
         // final CSR offsets of every sequence that starts in this tile
         for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
             u64 pos = base + (B.in_lds ? (u32)dseq[s - s_first] : drank(bstart(B.at(s))));
@@ -1695,6 +1779,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             A.sfix = sf > 0x7fffffffULL ? 0x7fffffffu : (u32)sf; // smaller only coarsens the buckets
         }
         A.lut = ctx->d_lut + 256 * p->moltype;
+        A.upper_only = p->moltype == KS_PROTEIN ? 1u : 0u;
         A.counts = counts;
         A.span = SK_TILE; A.c_div = 1; A.c_rcp = 0; A.out_cap = out_cap; A.max_len_tile = 0xffffffffu; A.R = 1;
         A.ticket = ticket; A.total_out = d_stats + 23;

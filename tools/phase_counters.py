@@ -28,7 +28,7 @@ def main():
         return
     base = sys.argv[1]
     prev = None
-    print("| phase | VALU | SALU | LDS | cumulative wave quad-cycles |\n|---|---|---|---|---|")
+    print("| phase | VALU | SALU | LDS | LDS active cycles | of them bank conflicts | cumulative wave quad-cycles |\n|---|---|---|---|---|---|---|")
     for i, n in enumerate(["0", "1", "2", "3", "4", "5", "6", "7", "full"]):
         f = glob.glob(os.path.join(base, f"ph_{n}", "*", "*_counter_collection.csv"))
         if not f:
@@ -39,8 +39,9 @@ def main():
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         w = sum(acc["SQ_WAVES"]) / len(acc["SQ_WAVES"])
         d = {k: sum(v) / len(v) / w for k, v in acc.items() if k != "SQ_WAVES"}
-        dv = [d[c] - (prev[c] if prev else 0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")]
-        print(f"| {PHASES[i]} | {dv[0]:.0f} | {dv[1]:.0f} | {dv[2]:.0f} | {d['SQ_WAVE_CYCLES']:.0f} |")
+        cols = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT")
+        dv = [d.get(c, 0) - (prev.get(c, 0) if prev else 0) for c in cols]
+        print(f"| {PHASES[i]} | {dv[0]:.0f} | {dv[1]:.0f} | {dv[2]:.0f} | {dv[3]:.0f} | {dv[4]:.0f} | {d['SQ_WAVE_CYCLES']:.0f} |")
         prev = d
 
 
