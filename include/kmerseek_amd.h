@@ -12,7 +12,10 @@
  *
  * Conventions
  *   - every function returns a ks_status (0 = ok) unless documented otherwise; nothing throws
- *     or aborts across this boundary; ks_last_error(ctx) gives the message of the last failure.
+ *     or aborts across this boundary — every entry point that can allocate runs its body inside an
+ *     exception guard (std::bad_alloc -> KS_ERR_OOM, anything else -> KS_ERR_HIP "internal error");
+ *     ks_last_error(ctx) gives the message of the last failure.  Reference convention: every failure
+ *     is a value (src/rust/errors.rs:8-24).
  *   - a ks_ctx owns one HIP device + one stream + a grow-only device workspace.  It is NOT
  *     thread-safe: use one context per host thread (the reference's `&self` + rayon fan-out,
  *     src/rust/index.rs:990-1005, becomes one batched call).
@@ -102,6 +105,12 @@ int ks_ctx_sketch_stats(const ks_ctx *ctx, uint64_t out[4]);
  * (the list is sized from the previous search of the context), out[1] = searches whose row pass was repeated with
  * ticket-ordered tiles because a look-back gave up (the context then uses tickets for good). */
 int ks_ctx_search_stats(const ks_ctx *ctx, uint64_t out[2]);
+/* Diagnostics: the KS_DEBUG_* environment variables (they force the rarely taken paths in the tests; results never
+ * depend on them) are read once, when the context is created — never on the per-call path.  This reads them again. */
+int ks_ctx_reload_debug_env(ks_ctx *ctx);
+/* Self-test of the exception guard, callable without a device: a body that throws `what` ("bad_alloc", "runtime", "other";
+ * anything else throws nothing) runs behind the guard; returns the status that came out of it. */
+int ks_debug_guard_selftest(const char *what);
 
 /* Plain device buffers for callers that have no HIP binding of their own (the *_device entry points take raw
  * device pointers): 256-byte aligned allocations on ctx's device, stream-ordered copies that return when done. */

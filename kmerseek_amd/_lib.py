@@ -61,6 +61,8 @@ SIGNATURES = {
     "ks_ctx_synchronize": (C.c_int, [_vp]),
     "ks_ctx_sketch_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
     "ks_ctx_search_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
+    "ks_ctx_reload_debug_env": (C.c_int, [_vp]),
+    "ks_debug_guard_selftest": (C.c_int, [C.c_char_p]),
     "ks_host_alloc": (C.c_int, [_vp, C.c_uint64, _pp]),
     "ks_host_free": (C.c_int, [_vp, _vp]),
     "ks_dev_malloc": (C.c_int, [_vp, C.c_uint64, _pp]),

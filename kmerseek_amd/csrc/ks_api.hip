@@ -8,18 +8,22 @@
 extern "C" int ks_sketch_batch_device(ks_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_seq_offsets,
                                       uint32_t n_seqs, uint64_t n_residues, uint32_t max_seq_len,
                                       const ks_params *params, ks_sketches **out) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, params, 0, out);
+    });
 }
 
 extern "C" int ks_sketch_queries_device(ks_ctx *ctx, const ks_index *index, const uint8_t *d_residues,
                                         const uint64_t *d_seq_offsets, uint32_t n_seqs, uint64_t n_residues,
                                         uint32_t max_seq_len, ks_sketches **out) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!index || !out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, &index->params,
-                                 ks_join_pbits(index->n_postings), out);
+                                 index->pbits, out);
+    });
 }
 
 static int upload_batch(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_offsets, uint32_t n_seqs,
@@ -47,6 +51,7 @@ static int upload_batch(ks_ctx *ctx, const uint8_t *residues, const uint64_t *se
 
 extern "C" int ks_sketch_batch(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_offsets, uint32_t n_seqs,
                                const ks_params *params, ks_sketches **out) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
     KS_TRY(ks_check_params(ctx, params));
@@ -60,12 +65,16 @@ extern "C" int ks_sketch_batch(ks_ctx *ctx, const uint8_t *residues, const uint6
     ks_pool_free(ctx, d_res);
     ks_pool_free(ctx, d_offs);
     return st;
+    });
 }
 
 extern "C" uint32_t ks_sketches_n_seqs(const ks_sketches *s) { return s ? s->n_seqs : 0; }
 extern "C" uint64_t ks_sketches_n_hashes(const ks_sketches *s) { return s ? s->n_hashes : 0; }
 extern "C" uint64_t ks_sketches_n_windows(const ks_sketches *s) { return s ? s->n_windows : 0; }
-extern "C" int ks_sketches_has_postings(const ks_sketches *s) { return (s && s->part_keys) ? 1 : 0; }
+extern "C" int ks_sketches_has_postings(const ks_sketches *s) {
+    return ks_guard(nullptr, [&]() -> int { return (s && s->part_keys) ? 1 : 0; 
+    });
+}
 extern "C" void ks_sketches_params(const ks_sketches *s, ks_params *out) { if (s && out) *out = s->params; }
 extern "C" const uint64_t *ks_sketches_device_offsets(const ks_sketches *s) { return s ? s->d_offsets : nullptr; }
 extern "C" const uint64_t *ks_sketches_device_hashes(const ks_sketches *s) { return s ? s->d_hashes : nullptr; }
@@ -73,6 +82,7 @@ extern "C" const uint32_t *ks_sketches_device_abunds(const ks_sketches *s) { ret
 
 extern "C" int ks_sketches_copy_to_host(ks_ctx *ctx, const ks_sketches *s, uint64_t *offsets, uint64_t *hashes,
                                         uint32_t *abunds) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx || !s) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     if (offsets) KS_HIP(ctx, hipMemcpyAsync(offsets, s->d_offsets, ((size_t)s->n_seqs + 1) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
@@ -80,10 +90,12 @@ extern "C" int ks_sketches_copy_to_host(ks_ctx *ctx, const ks_sketches *s, uint6
     if (abunds && s->n_hashes) KS_TRY(ks_copy_d2h(ctx, abunds, s->d_abunds, (size_t)s->n_hashes * sizeof(u32)));
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
+    });
 }
 
 extern "C" int ks_sketches_from_host(ks_ctx *ctx, const uint64_t *offsets, const uint64_t *hashes, const uint32_t *abunds,
                                      uint32_t n_seqs, const ks_params *params, ks_sketches **out) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!offsets || !out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     KS_TRY(ks_check_params(ctx, params));
@@ -118,11 +130,14 @@ extern "C" int ks_sketches_from_host(ks_ctx *ctx, const uint64_t *offsets, const
     if (e != hipSuccess) { ks_sketches_free(S); return ks_fail(ctx, KS_ERR_HIP, "upload failed: %s", hipGetErrorString(e)); }
     *out = S;
     return KS_OK;
+    });
 }
 
 extern "C" int ks_sketches_union(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     return ks_union_impl(ctx, in, out);
+    });
 }
 
 extern "C" void ks_sketches_free(ks_sketches *s) {
@@ -164,6 +179,7 @@ int ks_kmerpos_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 
 
 extern "C" int ks_kmer_positions(ks_ctx *ctx, const uint8_t *residues, const uint64_t *seq_offsets, uint32_t n_seqs,
                                  const ks_params *params, ks_kmerpos **out) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
     KS_TRY(ks_check_params(ctx, params));
@@ -177,19 +193,23 @@ extern "C" int ks_kmer_positions(ks_ctx *ctx, const uint8_t *residues, const uin
     ks_pool_free(ctx, d_res);
     ks_pool_free(ctx, d_offs);
     return st;
+    });
 }
 
 extern "C" int ks_kmer_positions_device(ks_ctx *ctx, const uint8_t *d_residues, const uint64_t *d_seq_offsets, uint32_t n_seqs,
                                         uint64_t n_residues, const ks_params *params, ks_kmerpos **out) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
     if (n_seqs && (!d_seq_offsets || (n_residues && !d_residues))) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL device buffer");
     return ks_kmerpos_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, params, out);
+    });
 }
 
 extern "C" uint64_t ks_kmerpos_count(const ks_kmerpos *p) { return p ? p->n : 0; }
 
 extern "C" int ks_kmerpos_copy_to_host(ks_ctx *ctx, const ks_kmerpos *p, uint32_t *seq, uint32_t *start, uint64_t *hash) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx || !p) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     if (p->n) {
@@ -199,6 +219,7 @@ extern "C" int ks_kmerpos_copy_to_host(ks_ctx *ctx, const ks_kmerpos *p, uint32_
     }
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
+    });
 }
 
 extern "C" void ks_kmerpos_free(ks_kmerpos *p) {
@@ -213,8 +234,10 @@ extern "C" void ks_kmerpos_free(ks_kmerpos *p) {
 // index + search
 // ---------------------------------------------------------------------------------------------
 extern "C" int ks_index_build(ks_ctx *ctx, const ks_sketches *targets, ks_index **out) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     return ks_index_build_impl(ctx, targets, out);
+    });
 }
 extern "C" uint32_t ks_index_n_targets(const ks_index *ix) { return ix ? ix->n_targets : 0; }
 extern "C" uint64_t ks_index_n_postings(const ks_index *ix) { return ix ? ix->n_postings : 0; }
@@ -231,14 +254,20 @@ extern "C" void ks_index_free(ks_index *ix) {
 }
 
 extern "C" int ks_search(ks_ctx *ctx, const ks_index *index, const ks_sketches *queries, ks_hits **out) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     return ks_search_impl(ctx, index, queries, out);
+    });
 }
 extern "C" uint64_t ks_hits_count(const ks_hits *h) { return h ? h->n_hits : 0; }
 extern "C" uint64_t ks_hits_n_pair_instances(const ks_hits *h) { return h ? h->n_pair_instances : 0; }
-extern "C" int ks_hits_partition_path(const ks_hits *h) { return h ? h->partition_path : -1; }
+extern "C" int ks_hits_partition_path(const ks_hits *h) {
+    return ks_guard(nullptr, [&]() -> int { return h ? h->partition_path : -1; 
+    });
+}
 extern "C" int ks_hits_copy_to_host(ks_ctx *ctx, const ks_hits *h, uint32_t *qid, uint32_t *tid, uint32_t *intersect,
                                     uint64_t *n_weighted) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx || !h) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)h->n_hits;
@@ -250,6 +279,7 @@ extern "C" int ks_hits_copy_to_host(ks_ctx *ctx, const ks_hits *h, uint32_t *qid
     }
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
+    });
 }
 extern "C" const uint32_t *ks_hits_device_qid(const ks_hits *h) { return h ? h->d_qid : nullptr; }
 extern "C" const uint32_t *ks_hits_device_tid(const ks_hits *h) { return h ? h->d_tid : nullptr; }
@@ -263,6 +293,7 @@ __global__ __launch_bounds__(256) void k_copy_add_u32(const u32 *in, u32 *out, u
 
 extern "C" int ks_hits_copy_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qid_base, uint32_t tid_base, uint32_t *d_qid,
                                       uint32_t *d_tid, uint32_t *d_intersect, uint64_t *d_n_weighted) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx || !h) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     const u64 n = h->n_hits;
@@ -273,6 +304,7 @@ extern "C" int ks_hits_copy_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qi
     if (d_intersect) KS_HIP(ctx, hipMemcpyAsync(d_intersect, h->d_isect, (size_t)n * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
     if (d_n_weighted) KS_HIP(ctx, hipMemcpyAsync(d_n_weighted, h->d_nw, (size_t)n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
     return KS_OK;
+    });
 }
 
 // ---- packed transport records (multi-GPU hit exchange) ---------------------------------------------------------------
@@ -293,22 +325,33 @@ __global__ __launch_bounds__(256) void k_hits_pack64(const u32 *qid, const u32 *
         if (e < esc_cap) { esc_row[e] = (u32)i; esc_isect[e] = (u32)a; esc_nw[e] = b; }
         a = vmax; b = vmax;
     }
-    packed[i] = ((((u64)(qid[i] + qid_base) << tbits) | (u64)(tid[i] + tid_base)) << (2 * vbits)) | (a << vbits) | b;
+    const u64 q = (u64)qid[i] + qid_base, t = (u64)tid[i] + tid_base;
+    // an id that does not fit its field (id_counts smaller than the real global range) would spill into its neighbour:
+    // the escape count is pushed beyond any capacity instead, so every rank takes the unpacked exchange
+    if ((q >> (64 - tbits - 2 * vbits)) != 0 || (t >> tbits) != 0) atomicOr(n_esc, 0x80000000u);
+    packed[i] = (((q << tbits) | t) << (2 * vbits)) | (a << vbits) | b;
 }
 
 extern "C" int ks_hits_pack64_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qid_base, uint32_t tid_base, int qbits, int tbits,
                                         uint64_t *d_packed, uint32_t *d_esc_row, uint32_t *d_esc_intersect, uint64_t *d_esc_n_weighted,
                                         uint32_t *d_n_esc, uint32_t esc_cap) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx || !h) return KS_ERR_INVALID_ARG;
     if (qbits < 1 || tbits < 1 || qbits + tbits > 48) return ks_fail(ctx, KS_ERR_INVALID_ARG, "pack64: %d + %d id bits leave fewer than 8 value bits", qbits, tbits);
     KS_HIP(ctx, hipSetDevice(ctx->device));
     const u64 n = h->n_hits;
+    if (!d_n_esc) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    // the escape counter is cleared HERE, on the context's stream: a caller that zeroes its buffer on another stream
+    // (torch's) is not ordered before this launch
+    KS_HIP(ctx, hipMemsetAsync(d_n_esc, 0, sizeof(u32), ctx->stream));
     if (n == 0) return KS_OK;
-    if (!d_packed || !d_n_esc || (esc_cap && (!d_esc_row || !d_esc_intersect || !d_esc_n_weighted))) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    if (n >= 0xffffffffULL) return ks_fail(ctx, KS_ERR_CAPACITY, "pack64: %llu rows (escape rows are 32-bit indices)", (unsigned long long)n);
+    if (!d_packed || (esc_cap && (!d_esc_row || !d_esc_intersect || !d_esc_n_weighted))) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     KS_LAUNCH(ctx, "hits_pack", k_hits_pack64, (u32)((n + 255) / 256), 256, (const u32 *)h->d_qid, (const u32 *)h->d_tid, (const u32 *)h->d_isect,
               (const u64 *)h->d_nw, n, qid_base, tid_base, tbits, (64 - qbits - tbits) / 2, d_packed, d_esc_row, d_esc_intersect, d_esc_n_weighted,
               d_n_esc, esc_cap);
     return KS_OK;
+    });
 }
 
 // the inverse, for the receiving side of the exchange: words -> columns (escaped rows keep the all-ones markers: the caller
@@ -326,6 +369,7 @@ __global__ __launch_bounds__(256) void k_hits_unpack64(const u64 *packed, u64 n,
 
 extern "C" int ks_hits_unpack64_device(ks_ctx *ctx, const uint64_t *d_packed, uint64_t n, int qbits, int tbits, uint32_t *d_qid,
                                        uint32_t *d_tid, uint32_t *d_intersect, uint64_t *d_n_weighted) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (qbits < 1 || tbits < 1 || qbits + tbits > 48) return ks_fail(ctx, KS_ERR_INVALID_ARG, "unpack64: %d + %d id bits leave fewer than 8 value bits", qbits, tbits);
     if (n == 0) return KS_OK;
@@ -335,6 +379,7 @@ extern "C" int ks_hits_unpack64_device(ks_ctx *ctx, const uint64_t *d_packed, ui
     KS_LAUNCH(ctx, "hits_unpack", k_hits_unpack64, (u32)((n + 255) / 256), 256, (const u64 *)d_packed, n, qbits, tbits, (64 - qbits - tbits) / 2,
               d_qid, d_tid, d_intersect, (u64 *)d_n_weighted);
     return KS_OK;
+    });
 }
 
 extern "C" void ks_hits_free(ks_hits *h) {

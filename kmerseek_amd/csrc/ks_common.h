@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -35,12 +37,35 @@ struct ks_timer_slot {
 
 struct ks_copy_engine; // ks_copy.hip: pinned staging + host copy threads for pageable host buffers
 
+// Diagnostic knobs (the KS_DEBUG_* environment variables: they force the rarely taken paths in the tests; results never
+// depend on them).  They are read ONCE, into the context, when it is created — never on the per-call path, so a stray
+// variable cannot switch kernels under a running service — and again only on request (ks_ctx_reload_debug_env: the tests
+// switch paths on one context).
+#define KS_DBG_LIST(X)                                                                                                   \
+    X(STAGED_H2D) X(PLAIN_COPIES) X(PAIRS_LSD) X(MSD_LDS_CAP) X(SCAN_3PASS) X(INDEX_LSD) X(JOIN_FP) X(FP_COARSEN)        \
+    X(PAIR_LIMIT) X(PBITS_MAX) X(UNPACKED_PAIRS) X(ONE_CURSOR) X(JOIN_SEGS) X(JOIN_SEG_CAP) X(JOIN_SPARSE) X(UNFUSED_ROWS) \
+    X(NO_ROWS_HINT) X(ROWS_TICKET) X(FORCE_ROWS_TICKET_RETRY) X(FORCE_TICKET_RETRY) X(NO_PLAN) X(NO_COMPACT) X(SPAN)      \
+    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(NO_FUSED_STEP) X(LOOKBACK_SKIP)
+enum ks_dbg_id {
+#define KS_DBG_ENUM(n) KS_DBG_##n,
+    KS_DBG_LIST(KS_DBG_ENUM)
+#undef KS_DBG_ENUM
+    KS_DBG_COUNT
+};
+struct ks_debug {
+    bool set[KS_DBG_COUNT];
+    char val[KS_DBG_COUNT][32];
+};
+void ks_debug_load(ks_debug *d); // ks_ctx.hip
+
 struct ks_ctx {
     int device = 0;
     ks_copy_engine *copy = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int n_cus = 256;
+    ks_debug dbg;            // KS_DEBUG_* as they were when the context was created
+    u64 pool_cap = 0;        // KS_DEBUG_POOL_CAP: the pool refuses to hold more device bytes than this (0 = no cap)
     std::string err;
     std::vector<ks_pool_block> pool;
     u64 pool_mallocs = 0; // hipMalloc calls made by the pool (0 in steady state)
@@ -82,6 +107,28 @@ void ks_pool_free(ks_ctx *ctx, void *ptr);
 void ks_pool_trim(ks_ctx *ctx);
 
 int ks_fail(ks_ctx *ctx, int status, const char *fmt, ...);
+// value of a diagnostic knob as the context holds it, or nullptr (drop-in for getenv("KS_DEBUG_" #name))
+static inline const char *ks_dbg(const ks_ctx *ctx, int id) { return (ctx && ctx->dbg.set[id]) ? ctx->dbg.val[id] : nullptr; }
+
+// Every extern "C" entry point that can allocate host memory (new, std::vector / std::string growth in the context, the
+// pool's block list, timers) runs its body inside this guard: a C++ exception never unwinds into the caller's frames
+// (Rust, ctypes: that is std::terminate).  bad_alloc -> KS_ERR_OOM, anything else -> KS_ERR_HIP "internal error".
+// Reference convention: every failure is a value (src/rust/errors.rs:8-24).
+int ks_guard_fail(ks_ctx *ctx, int status, const char *what) noexcept;
+void ks_guard_enter(ks_ctx *ctx); // KS_DEBUG_THROW (tests): throws the named exception from inside the guard
+template <typename F>
+static inline int ks_guard(ks_ctx *ctx, F &&body) noexcept {
+    try {
+        ks_guard_enter(ctx);
+        return body();
+    } catch (const std::bad_alloc &) {
+        return ks_guard_fail(ctx, KS_ERR_OOM, "out of host memory (std::bad_alloc)");
+    } catch (const std::exception &e) {
+        return ks_guard_fail(ctx, KS_ERR_HIP, e.what());
+    } catch (...) {
+        return ks_guard_fail(ctx, KS_ERR_HIP, "unknown exception");
+    }
+}
 
 void ks_timer_begin(ks_ctx *ctx, const char *name);
 void ks_timer_end(ks_ctx *ctx);
@@ -243,7 +290,7 @@ int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_
 int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,
                           u32 max_seq_len, const ks_params *p, int part_pbits, ks_sketches **out);
 // bits of hash prefix the join against an index of n_postings uses (buckets of ~3k index postings, <= 16)
-int ks_join_pbits(u64 n_postings);
+int ks_join_pbits(const ks_ctx *ctx, u64 n_postings);
 // multiplier of ks_join_prefix (ks_device.h) for a join on pbits prefix bits of hashes kept below max_hash
 u32 ks_join_prefix_mul(int pbits, u64 max_hash);
 int ks_kmerpos_tiles_launch(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, const ks_params *p, u32 *d_seq,

@@ -116,7 +116,7 @@ int ks_copy_h2d(ks_ctx *ctx, void *dst, const void *src, size_t bytes) {
     // Measured (MI355X box, 310 MB of residues): the runtime's own pageable upload already runs near link rate (the source
     // pages are warm), and staging it through host threads is slower — unlike the download direction, where the runtime
     // manages ~17 GB/s and the staged path 53 GB/s.  So uploads are staged only on request.
-    ks_copy_engine *e = (bytes >= ((size_t)4 << 20) && getenv("KS_DEBUG_STAGED_H2D") && !host_is_pinned(src)) ? engine(ctx) : nullptr;
+    ks_copy_engine *e = (bytes >= ((size_t)4 << 20) && ks_dbg(ctx, KS_DBG_STAGED_H2D) && !host_is_pinned(src)) ? engine(ctx) : nullptr;
     if (!e) { // the default: one copy
         KS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
         return KS_OK;
@@ -135,7 +135,7 @@ int ks_copy_h2d(ks_ctx *ctx, void *dst, const void *src, size_t bytes) {
 // Returns when dst holds the data.
 int ks_copy_d2h(ks_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!bytes) return KS_OK;
-    ks_copy_engine *e = (bytes >= ((size_t)4 << 20) && !host_is_pinned(dst) && !getenv("KS_DEBUG_PLAIN_COPIES")) ? engine(ctx) : nullptr;
+    ks_copy_engine *e = (bytes >= ((size_t)4 << 20) && !host_is_pinned(dst) && !ks_dbg(ctx, KS_DBG_PLAIN_COPIES)) ? engine(ctx) : nullptr;
     if (!e) {
         KS_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -157,13 +157,17 @@ int ks_copy_d2h(ks_ctx *ctx, void *dst, const void *src, size_t bytes) {
 }
 
 extern "C" int ks_host_alloc(ks_ctx *ctx, uint64_t bytes, void **out) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx || !out) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     if (hipHostMalloc(out, bytes ? bytes : 64) != hipSuccess) { (void)hipGetLastError(); return ks_fail(ctx, KS_ERR_OOM, "hipHostMalloc(%llu) failed", (unsigned long long)bytes); }
     return KS_OK;
+    });
 }
 extern "C" int ks_host_free(ks_ctx *ctx, void *ptr) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (ptr) KS_HIP(ctx, hipHostFree(ptr));
     return KS_OK;
+    });
 }

@@ -13,7 +13,9 @@ int ks_fail(ks_ctx *ctx, int status, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    if (ctx) {
+        try { ctx->err = buf; } catch (...) { } // (the status code still says what happened)
+    }
     return status;
 }
 
@@ -37,11 +39,13 @@ extern "C" const char *ks_status_string(int s) {
 
 // get_hash_function_from_moltype, src/rust/encoding.rs:17-27
 extern "C" int ks_moltype_from_string(const char *name, uint32_t *out) {
+    return ks_guard(nullptr, [&]() -> int {
     if (!name || !out) return KS_ERR_INVALID_ARG;
     if (!strcmp(name, "protein") || !strcmp(name, "raw")) { *out = KS_PROTEIN; return KS_OK; }
     if (!strcmp(name, "hp")) { *out = KS_HP; return KS_OK; }
     if (!strcmp(name, "dayhoff")) { *out = KS_DAYHOFF; return KS_OK; }
     return KS_ERR_INVALID_MOLTYPE;
+    });
 }
 
 // sourmash max_hash_for_scaled: (u64::MAX as f64 / scaled as f64) as u64, saturating
@@ -95,6 +99,61 @@ static void build_luts(u8 *lut) {
         }
 }
 
+// ---- diagnostic knobs: read once (see ks_common.h) ------------------------------------------
+void ks_debug_load(ks_debug *d) {
+    static const char *const names[KS_DBG_COUNT] = {
+#define KS_DBG_NAME(n) "KS_DEBUG_" #n,
+        KS_DBG_LIST(KS_DBG_NAME)
+#undef KS_DBG_NAME
+    };
+    for (int i = 0; i < KS_DBG_COUNT; i++) {
+        const char *v = getenv(names[i]);
+        d->set[i] = v != nullptr;
+        d->val[i][0] = 0;
+        if (v) { strncpy(d->val[i], v, sizeof d->val[i] - 1); d->val[i][sizeof d->val[i] - 1] = 0; }
+    }
+}
+static void debug_apply(ks_ctx *ctx) {
+    ks_debug_load(&ctx->dbg);
+    const char *cap = ks_dbg(ctx, KS_DBG_POOL_CAP);
+    ctx->pool_cap = cap ? strtoull(cap, nullptr, 10) : 0;
+}
+extern "C" int ks_ctx_reload_debug_env(ks_ctx *ctx) {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    debug_apply(ctx);
+    return KS_OK;
+}
+
+// ---- exception guard of the extern "C" boundary (see ks_common.h) ---------------------------
+int ks_guard_fail(ks_ctx *ctx, int status, const char *what) noexcept {
+    if (ctx) {
+        try {
+            ctx->err.assign(status == KS_ERR_OOM ? "" : "internal error: ");
+            ctx->err.append(what ? what : "?");
+        } catch (...) { // (no memory even for the message: the status code still says what happened)
+        }
+    }
+    return status;
+}
+void ks_guard_enter(ks_ctx *ctx) {
+    const char *t = ks_dbg(ctx, KS_DBG_THROW);
+    if (!t) return;
+    if (!strcmp(t, "bad_alloc")) throw std::bad_alloc();
+    if (!strcmp(t, "runtime")) throw std::runtime_error("KS_DEBUG_THROW");
+    if (!strcmp(t, "other")) throw 42;
+}
+
+// Self-test of the guard, callable without a device (tests/test_abi.py): runs a body that throws the named exception
+// ("bad_alloc", "runtime", "other"; anything else: throws nothing) through ks_guard and returns the status that came out.
+extern "C" int ks_debug_guard_selftest(const char *what) {
+    return ks_guard(nullptr, [&]() -> int {
+        if (what && !strcmp(what, "bad_alloc")) { std::vector<char> v; v.reserve((size_t)-1 / 2); } // (length_error / bad_alloc: a real failed reservation)
+        if (what && !strcmp(what, "runtime")) throw std::runtime_error("selftest");
+        if (what && !strcmp(what, "other")) throw 42;
+        return KS_OK;
+    });
+}
+
 // ---------------------------------------------------------------------------------------------
 extern "C" int ks_ctx_create(int device, void *hip_stream, ks_ctx **out) {
     if (!out) return KS_ERR_INVALID_ARG;
@@ -102,8 +161,11 @@ extern "C" int ks_ctx_create(int device, void *hip_stream, ks_ctx **out) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return KS_ERR_NO_DEVICE;
     if (device < 0 || device >= n) return KS_ERR_INVALID_ARG;
-    ks_ctx *ctx = new ks_ctx();
+    ks_ctx *ctx = new (std::nothrow) ks_ctx();
+    if (!ctx) return KS_ERR_OOM;
     ctx->device = device;
+    try { ctx->err.reserve(640); ctx->pool.reserve(256); } catch (...) { delete ctx; return KS_ERR_OOM; }
+    debug_apply(ctx);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cus = prop.multiProcessorCount;
@@ -141,13 +203,16 @@ extern "C" void ks_ctx_destroy(ks_ctx *ctx) {
 extern "C" const char *ks_last_error(const ks_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 extern "C" void *ks_ctx_stream(const ks_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 extern "C" int ks_ctx_synchronize(ks_ctx *ctx) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
+    });
 }
 
 extern "C" int ks_ctx_pool_stats(const ks_ctx *ctx, uint64_t *n_blocks, uint64_t *bytes_held, uint64_t *bytes_in_use,
                                  uint64_t *n_mallocs) {
+    return ks_guard((ks_ctx *)ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     u64 held = 0, used = 0;
     for (auto &b : ctx->pool) { held += b.size; if (b.in_use) used += b.size; }
@@ -156,46 +221,59 @@ extern "C" int ks_ctx_pool_stats(const ks_ctx *ctx, uint64_t *n_blocks, uint64_t
     if (bytes_in_use) *bytes_in_use = used;
     if (n_mallocs) *n_mallocs = ctx->pool_mallocs;
     return KS_OK;
+    });
 }
 
 extern "C" int ks_ctx_sketch_stats(const ks_ctx *ctx, uint64_t out[4]) {
+    return ks_guard((ks_ctx *)ctx, [&]() -> int {
     if (!ctx || !out) return KS_ERR_INVALID_ARG;
     out[0] = ctx->sketch_ticket_fallbacks; out[1] = ctx->sketch_use_ticket ? 1 : 0;
     out[2] = ctx->sketch_compact_fallbacks; out[3] = ctx->sketch_cap_fallbacks;
     return KS_OK;
+    });
 }
 
 extern "C" int ks_ctx_search_stats(const ks_ctx *ctx, uint64_t out[2]) {
+    return ks_guard((ks_ctx *)ctx, [&]() -> int {
     if (!ctx || !out) return KS_ERR_INVALID_ARG;
     out[0] = ctx->join_retries; out[1] = ctx->rows_ticket_fallbacks;
     return KS_OK;
+    });
 }
 
 extern "C" int ks_dev_malloc(ks_ctx *ctx, uint64_t bytes, void **out) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx || !out) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     if (hipMalloc(out, bytes ? bytes : 256) != hipSuccess) { (void)hipGetLastError(); return ks_fail(ctx, KS_ERR_OOM, "hipMalloc(%llu) failed", (unsigned long long)bytes); }
     return KS_OK;
+    });
 }
 extern "C" int ks_dev_free(ks_ctx *ctx, void *ptr) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     KS_HIP(ctx, hipFree(ptr));
     return KS_OK;
+    });
 }
 extern "C" int ks_dev_upload(ks_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx || (bytes && (!dst || !src))) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     KS_TRY(ks_copy_h2d(ctx, dst, src, (size_t)bytes));
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
+    });
 }
 extern "C" int ks_dev_download(ks_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx || (bytes && (!dst || !src))) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     KS_TRY(ks_copy_d2h(ctx, dst, src, (size_t)bytes));
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
+    });
 }
 
 // ---- pool ---------------------------------------------------------------------------------
@@ -210,6 +288,14 @@ void *ks_pool_alloc(ks_ctx *ctx, size_t bytes) {
     }
     if (best >= 0) { ctx->pool[best].in_use = true; return ctx->pool[best].ptr; }
     size_t want = bytes < (1u << 20) ? bytes : ((bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1));
+    if (ctx->pool_cap) { // KS_DEBUG_POOL_CAP (tests): behave like a device that is full
+        size_t held = 0;
+        for (auto &b : ctx->pool) held += b.size;
+        if (held + want > ctx->pool_cap) {
+            ks_fail(ctx, KS_ERR_OOM, "device pool cap: %zu bytes held, %zu wanted, cap %llu", held, want, (unsigned long long)ctx->pool_cap);
+            return nullptr;
+        }
+    }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) { // give cached blocks back and retry once
@@ -297,21 +383,26 @@ void ks_timer_end(ks_ctx *ctx) {
 }
 
 extern "C" int ks_timing_enable(ks_ctx *ctx, int enable) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!enable) timer_resolve(ctx);
     ctx->timing = enable < 0 ? 0 : (enable > 2 ? 1 : enable);
     return KS_OK;
+    });
 }
 
 extern "C" int ks_timing_reset(ks_ctx *ctx) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     timer_resolve(ctx);
     for (auto &v : ctx->t_ms) v = 0.0;
     for (auto &v : ctx->t_launches) v = 0;
     return KS_OK;
+    });
 }
 
 extern "C" int ks_timing_get(ks_ctx *ctx, ks_kernel_time *rows, uint32_t cap, uint32_t *n) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx || !n) return KS_ERR_INVALID_ARG;
     timer_resolve(ctx);
     *n = (uint32_t)ctx->t_names.size();
@@ -322,6 +413,7 @@ extern "C" int ks_timing_get(ks_ctx *ctx, ks_kernel_time *rows, uint32_t cap, ui
         rows[i].total_ms = ctx->t_ms[i];
     }
     return KS_OK;
+    });
 }
 
 // ---- device ceilings for bench.py: u64 multiply rate, device copy rate ----
@@ -335,6 +427,7 @@ __global__ __launch_bounds__(256) void k_bench_u64_mul(u64 *out, u32 iters) {
 }
 
 extern "C" int ks_bench_device_rates(ks_ctx *ctx, double *gmul_per_s, double *copy_gb_per_s, double *nominal_gb_per_s) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     hipEvent_t e0, e1;
@@ -384,6 +477,7 @@ extern "C" int ks_bench_device_rates(ks_ctx *ctx, double *gmul_per_s, double *co
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return st;
+    });
 }
 
 // ---- random-gather rates (SURVEY §7's "small-alphabet table path" for hp: a rolling 24-bit window index into a table of
@@ -401,6 +495,7 @@ __global__ __launch_bounds__(256) void k_bench_gather(const u64 *table, u64 mask
 
 // gathers_per_s[0]: random 8-byte gathers from a 134 MB table; [1]: from a 2 MB table (fits one XCD's L2)
 extern "C" int ks_bench_gather_rates(ks_ctx *ctx, double *gathers_per_s) {
+    return ks_guard(ctx, [&]() -> int {
     if (!ctx || !gathers_per_s) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
     hipEvent_t e0, e1;
@@ -429,6 +524,7 @@ extern "C" int ks_bench_gather_rates(ks_ctx *ctx, double *gathers_per_s) {
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return st;
+    });
 }
 
 // ---- host-side pre-step: AminoAcidAmbiguity::validate_and_resolve, src/rust/aminoacid.rs:74-105 ----
@@ -441,6 +537,7 @@ static inline u64 splitmix64(u64 *s) {
 
 extern "C" int ks_validate_and_resolve(const uint8_t *seq, uint64_t len, int upper, uint64_t rng_seed,
                                        uint8_t *out, uint64_t *out_len, ks_residue_error *err) {
+    return ks_guard(nullptr, [&]() -> int {
     if ((!seq && len) || !out || !out_len) return KS_ERR_INVALID_ARG;
     // class LUT: 0 invalid, 1 plain valid (20 standard + X U O), 2 stop, 3/4/5 = B/Z/J.  Called from many packer threads
     // at once (ks_ingest.cpp, ks_host.cpp): the table is a function-local static built by its initialiser (C++11
@@ -478,4 +575,5 @@ extern "C" int ks_validate_and_resolve(const uint8_t *seq, uint64_t len, int upp
     }
     *out_len = n;
     return KS_OK;
+    });
 }

@@ -511,7 +511,8 @@ static int fail_std(const std::exception &e, char *err, size_t cap) {
 #define KSH_GUARD(...)                                             \
     try { __VA_ARGS__; return 0; }                                 \
     catch (const IndexError &e) { return fail(e, err, err_cap); }  \
-    catch (const std::exception &e) { return fail_std(e, err, err_cap); }
+    catch (const std::exception &e) { return fail_std(e, err, err_cap); } \
+    catch (...) { if (err && err_cap) { strncpy(err, "internal error (unknown exception)", err_cap - 1); err[err_cap - 1] = 0; } return 1000; }
 
 static void json_str(std::ostringstream &o, const std::string &s) {
     o << '"';

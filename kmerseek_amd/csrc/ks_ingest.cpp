@@ -439,14 +439,28 @@ class Ingest {
         BoundedQueue<int> q_free(slots_.size() + 1), q_packed(slots_.size() + 1), q_dev(slots_.size() + 1), q_done(slots_.size() + 1);
         for (size_t i = 0; i < slots_.size(); i++) q_free.push((int)i);
         auto abort_all = [&] { q_raw.close(); q_free.close(); q_packed.close(); q_dev.close(); q_done.close(); };
-        std::thread t_read([&] {
+        // a stage that throws (std::bad_alloc from a growing vector, mostly) must not take the process down from inside a
+        // std::thread: the failure is recorded, every queue is closed, the other stages drain and the caller gets a code
+        auto stage_failed = [&](int code, const char *what) {
+            try { fail_.raise(code, what); } catch (...) { fail_.set.store(true); }
+            abort_all();
+        };
+        auto guarded = [&](auto body) {
+            return [&stage_failed, body]() {
+                try { body(); }
+                catch (const std::bad_alloc &) { stage_failed(13, "out of host memory"); }
+                catch (const std::exception &e) { stage_failed(1000, e.what()); }
+                catch (...) { stage_failed(1000, "unknown exception in an ingest stage"); }
+            };
+        };
+        std::thread t_read(guarded([&] {
             RawBatch b;
             while (!fail_.set.load() && read_batch(b))
                 if (!q_raw.push(std::move(b))) break;
             q_raw.close();
             if (fail_.set.load()) abort_all();
-        });
-        std::thread t_pack([&] {
+        }));
+        std::thread t_pack(guarded([&] {
             RawBatch b;
             int slot;
             while (q_raw.pop(b)) {
@@ -455,28 +469,30 @@ class Ingest {
                 if (!q_packed.push(slot)) break;
             }
             q_packed.close();
-        });
-        std::thread t_up([&] {
+        }));
+        std::thread t_up(guarded([&] {
             int slot;
             while (q_packed.pop(slot)) {
                 if (!upload(slots_[slot])) { abort_all(); return; }
                 if (!q_dev.push(slot)) break;
             }
             q_dev.close();
-        });
-        std::thread t_collect([&] {
+        }));
+        std::thread t_collect(guarded([&] {
             int slot;
             while (q_done.pop(slot)) {
                 if (!collect(slots_[slot])) { abort_all(); return; }
                 if (!q_free.push(slot)) break;
             }
-        });
+        }));
         // the device stage stays in the calling thread: ks_ctx is bound to the thread that issues its batches
-        int slot;
-        while (q_dev.pop(slot)) {
-            if (!sketch(slots_[slot])) { abort_all(); break; }
-            if (!q_done.push(slot)) break;
-        }
+        guarded([&] {
+            int slot;
+            while (q_dev.pop(slot)) {
+                if (!sketch(slots_[slot])) { abort_all(); break; }
+                if (!q_done.push(slot)) break;
+            }
+        })();
         q_done.close();
         t_collect.join();
         abort_all();
@@ -521,16 +537,28 @@ extern "C" int ksh_sketch_fasta(const char *fasta_path, uint32_t ksize, uint32_t
         return fail(2, std::string("Invalid moltype: ") + moltype + ". Must be one of: protein, dayhoff, hp");
     if (ksize == 0 || ksize > 128) return fail(4, "Invalid ksize");
     if (scaled == 0) return fail(12, "scaled must be >= 1");
-    ksh_fasta_sketches *R = new ksh_fasta_sketches();
-    std::string e;
-    int rc;
-    {
-        Ingest ing(fasta_path, ksize, scaled, mt, validate, device, batch_residues, pipeline, R);
-        rc = ing.run(e);
+    // nothing throws across this boundary (include/kmerseek_host_c.h): 13 = out of host memory, 1000 = any other exception
+    ksh_fasta_sketches *R = nullptr;
+    try {
+        R = new ksh_fasta_sketches();
+        std::string e;
+        int rc;
+        {
+            Ingest ing(fasta_path, ksize, scaled, mt, validate, device, batch_residues, pipeline, R);
+            rc = ing.run(e);
+        }
+        if (rc != 0) { delete R; return fail(rc, e); }
+        *out = R;
+        return 0;
+    } catch (const std::bad_alloc &) {
+        delete R;
+        if (err && err_cap) { strncpy(err, "out of host memory", err_cap - 1); err[err_cap - 1] = 0; }
+        return 13;
+    } catch (...) {
+        delete R;
+        if (err && err_cap) { strncpy(err, "internal error (exception)", err_cap - 1); err[err_cap - 1] = 0; }
+        return 1000;
     }
-    if (rc != 0) { delete R; return fail(rc, e); }
-    *out = R;
-    return 0;
 }
 
 extern "C" uint64_t ksh_fs_n_records(const ksh_fasta_sketches *r) { return r ? r->names.size() : 0; }
@@ -540,7 +568,7 @@ extern "C" const uint64_t *ksh_fs_hashes(const ksh_fasta_sketches *r) { return r
 extern "C" const uint32_t *ksh_fs_abunds(const ksh_fasta_sketches *r) { return r ? r->abunds.p : nullptr; }
 extern "C" const char *ksh_fs_names(ksh_fasta_sketches *r, uint64_t *len) {
     if (!r) return nullptr;
-    if (r->names_blob.empty() && !r->names.empty()) {
+    if (r->names_blob.empty() && !r->names.empty()) try {
         size_t tot = 0;
         for (auto &n : r->names) tot += n.size() + 1;
         r->names_blob.reserve(tot);
@@ -548,6 +576,9 @@ extern "C" const char *ksh_fs_names(ksh_fasta_sketches *r, uint64_t *len) {
             if (i) r->names_blob += '\n';
             r->names_blob += r->names[i];
         }
+    } catch (...) { // (out of host memory for the joined blob)
+        if (len) *len = 0;
+        return nullptr;
     }
     if (len) *len = r->names_blob.size();
     return r->names_blob.c_str();

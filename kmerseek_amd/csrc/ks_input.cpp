@@ -160,8 +160,9 @@ extern "C" int ksh_input_decompress(const char *path, uint8_t **data, uint64_t *
     auto put = [](char *dst, uint32_t cap, const std::string &s) {
         if (dst && cap) { strncpy(dst, s.c_str(), cap - 1); dst[cap - 1] = 0; }
     };
-    if (!path || !data || !len) { put(err, err_cap, "NULL argument"); return 1; }
+    if (!path || !data || !len) { if (err && err_cap) { strncpy(err, "NULL argument", err_cap - 1); err[err_cap - 1] = 0; } return 1; }
     *data = nullptr; *len = 0;
+    try { // (nothing throws across the boundary: the strings below may allocate)
     std::string e;
     KsInput *in = KsInput::open(path, e);
     if (!in) { put(err, err_cap, "Parse error: " + e); return 11; }
@@ -186,6 +187,10 @@ extern "C" int ksh_input_decompress(const char *path, uint8_t **data, uint64_t *
     if (rc) { free(buf); return rc; }
     *data = buf; *len = n;
     return 0;
+    } catch (...) {
+        if (err && err_cap) { strncpy(err, "out of host memory", err_cap - 1); err[err_cap - 1] = 0; }
+        return 13;
+    }
 }
 
 extern "C" void ksh_input_free(uint8_t *data) { free(data); }

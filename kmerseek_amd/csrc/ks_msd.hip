@@ -371,8 +371,9 @@ __global__ __launch_bounds__(ML_THREADS) void k_msd_local_big(u64 *keys, u64 *sc
                     }
                 }
                 __syncthreads();
-                // the padding slots of a partial tile were counted under digit 255: only real records advance the cursors
-                if (tid == 255 && nv < ML_CAP) dcount[255] -= ML_CAP - nv;
+                // the padding slots (~0 keys) of a partial tile were counted under the pass's LARGEST digit — `mask`, which is
+                // 255 only when the pass has all 8 bits: only real records advance the cursors
+                if (tid == mask && nv < ML_CAP) dcount[mask] -= ML_CAP - nv;
                 __syncthreads();
                 cursor[tid] += dcount[tid];
                 __syncthreads();
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_msd_local_big(u64 *keys, u64 *sc
 // *done = 0 when the list is too small / the key too narrow for this path to pay (the caller takes the LSD sort).
 int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbits, int *done) {
     *done = 0;
-    if (nbits <= 16 || n < 65536 || n >= 0xffffffffULL || getenv("KS_DEBUG_PAIRS_LSD")) return KS_OK;
+    if (nbits <= 16 || n < 65536 || n >= 0xffffffffULL || ks_dbg(ctx, KS_DBG_PAIRS_LSD)) return KS_OK;
     // level 2 is as wide as it takes for ~768 records per bucket (0 .. 8 bits): a short list does not pay 65,536 buckets
     // ... and then as wide as it takes to save a local pass (remaining bits a multiple of 8): passes cost more than buckets
     int bits2 = 0;
@@ -402,7 +403,7 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
     const u32 mask2 = (1u << (8 + bits2)) - 1u, n_buckets = 1u << (8 + bits2);
     const u32 n_tiles = (u32)((n + MS_TILE - 1) / MS_TILE);
     u32 lds_cap = ML_CAP;
-    if (const char *f = getenv("KS_DEBUG_MSD_LDS_CAP")) { // exercises the large-bucket paths on small inputs
+    if (const char *f = ks_dbg(ctx, KS_DBG_MSD_LDS_CAP)) { // exercises the large-bucket paths on small inputs
         const u32 v = (u32)atoi(f);
         if (v >= 2 && v < ML_CAP) lds_cap = v;
     }

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn *in, T
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                if (flag == 0) { ticket[1] = 1; flag = SCAN_FLAG_PRE; val = 0; } // gave up: the host reports it
+                if (flag == 0) { atomicOr(&ticket[1], 1u); flag = SCAN_FLAG_PRE; val = 0; } // gave up: the host reports it
                 const u64 is_pre = __ballot(flag == SCAN_FLAG_PRE);
                 const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
                 u64 contrib = tid <= first ? val : 0;
@@ -201,7 +201,7 @@ static int scan_generic(ks_ctx *ctx, const TIn *in, TOut *out, u64 n, TOut *d_to
         KS_LAUNCH(ctx, "scan_apply", (k_scan_apply<TIn, TOut>), 1, SCAN_THREADS, in, out, (const TOut *)nullptr, n, d_total);
         return KS_OK;
     }
-    if (nblocks <= SCAN_RING / 2 && n < (1ULL << SCAN_VAL_BITS) && !getenv("KS_DEBUG_SCAN_3PASS")) {
+    if (nblocks <= SCAN_RING / 2 && n < (1ULL << SCAN_VAL_BITS) && !ks_dbg(ctx, KS_DBG_SCAN_3PASS)) {
         if (!ctx->scan_ring) {
             KS_HIP(ctx, hipMalloc((void **)&ctx->scan_ring, (size_t)SCAN_RING * sizeof(unsigned long long)));
             KS_HIP(ctx, hipMalloc((void **)&ctx->scan_ticket, 2 * sizeof(u32)));

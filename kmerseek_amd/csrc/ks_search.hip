@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_split_vals(const u64 *vals, u64 n, u32 
     if ((threadIdx.x & 63) == 0 && a > *max_abund) atomicMax(max_abund, a); // (plain read first: almost every wave's maximum is already covered)
 }
 
-int ks_join_pbits(u64 n_postings);
+int ks_join_pbits(const ks_ctx *ctx, u64 n_postings);
 __global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int pbits, u32 pfxK, u64 *dir);
 __global__ __launch_bounds__(256) void k_index_finish(const u64 *keys, const u32 *tids, const u32 *abunds, const u64 *dir, u64 n, int pbits,
                                                       u32 pfxK, int fp_shift, u32 *fp, ks_post *post);
@@ -84,7 +84,7 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
         // three passes: partition on the sort prefix twice, sort the buckets in LDS (ks_prims.hip)
         int overflowed = 0;
         IX_CHECK(ks_alloc(ctx, &k0, (size_t)n));
-        if (!getenv("KS_DEBUG_INDEX_LSD"))
+        if (!ks_dbg(ctx, KS_DBG_INDEX_LSD))
             IX_CHECK(ks_index_sort_partitioned(ctx, t->d_hashes, v0, n, ks_max_hash(t->params.scaled), k0, ix->d_tids, ix->d_abunds, d_max,
                                                &overflowed));
         else
@@ -115,7 +115,7 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
     }
     {
         // the join-bucket directory belongs to the index (its prefix width depends on the posting count alone)
-        ix->pbits = ks_join_pbits(n);
+        ix->pbits = ks_join_pbits(ctx, n);
         const u32 nb = 1u << ix->pbits;
         const u32 K = ks_join_prefix_mul(ix->pbits, ks_max_hash(t->params.scaled));
         IX_CHECK(ks_alloc(ctx, &ix->d_dir, (size_t)nb + 1));
@@ -125,13 +125,13 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
         IX_HIP(hipGetLastError());
         // Big indexes (>= 2^JN_FP_PBITS join buckets) are joined on 4-byte fingerprints (streamed) + 16-byte postings (fetched per
         // candidate match); the others keep the sorted columns (k_join_buckets_keys)
-        ix->fp_layout = ix->pbits >= JN_FP_PBITS || getenv("KS_DEBUG_JOIN_FP");
+        ix->fp_layout = ix->pbits >= JN_FP_PBITS || ks_dbg(ctx, KS_DBG_JOIN_FP);
         if (ix->fp_layout) {
         IX_CHECK(ks_alloc(ctx, &ix->d_fp, (size_t)(n ? n : 1)));
         IX_CHECK(ks_alloc(ctx, &ix->d_post, (size_t)(n ? n : 1)));
         ix->fp_shift = 32 - ix->pbits;
-        if (getenv("KS_DEBUG_FP_COARSEN")) {
-            ix->fp_shift += atoi(getenv("KS_DEBUG_FP_COARSEN"));
+        if (ks_dbg(ctx, KS_DBG_FP_COARSEN)) {
+            ix->fp_shift += atoi(ks_dbg(ctx, KS_DBG_FP_COARSEN));
             if (ix->fp_shift > 63) ix->fp_shift = 63;
         }
         IX_CHECK(ks_alloc(ctx, &ix->d_bmeta, (size_t)nb));
@@ -183,7 +183,7 @@ done:
 //                     1M-vs-1M workload with fewer registers than 12; 9 needs a second round for half of the buckets)
 // most records one match list may hold (32-bit offsets in the sort and the reduce); a debug override makes the
 // slicing path testable on small inputs
-#define KS_PAIR_LIMIT (getenv("KS_DEBUG_PAIR_LIMIT") ? strtoull(getenv("KS_DEBUG_PAIR_LIMIT"), nullptr, 10) : 0xfffffff0ULL)
+#define KS_PAIR_LIMIT (ks_dbg(ctx, KS_DBG_PAIR_LIMIT) ? strtoull(ks_dbg(ctx, KS_DBG_PAIR_LIMIT), nullptr, 10) : 0xfffffff0ULL)
 #ifndef JN_WLIST
 #define JN_WLIST 128
 #endif
@@ -207,9 +207,11 @@ static int bits_for(u32 n) { // bits needed to represent ids 0..n-1
     return b < 1 ? 1 : b;
 }
 
-int ks_join_pbits(u64 n_postings) { // buckets of ~3k index postings; the query side is partitioned on the same bits
-    // (8 bits by the sketch kernel + up to 9 by the bucket scatter; KS_DEBUG_PBITS_MAX is a tuning aid)
-    static const int cap = [] { const char *f = getenv("KS_DEBUG_PBITS_MAX"); const int v = f ? atoi(f) : 16; return v < 1 ? 1 : (v > 17 ? 17 : v); }();
+int ks_join_pbits(const ks_ctx *ctx, u64 n_postings) { // buckets of ~3k index postings; the query side is partitioned on the same bits
+    // (8 bits by the sketch kernel + up to 9 by the bucket scatter; KS_DEBUG_PBITS_MAX is a tuning aid.  An index keeps the
+    // width it was built with: ks_index::pbits)
+    int cap = 16;
+    if (const char *f = ks_dbg(ctx, KS_DBG_PBITS_MAX)) { const int v = atoi(f); cap = v < 1 ? 1 : (v > 17 ? 17 : v); }
     int pbits = 0;
     while (pbits < cap && (n_postings >> pbits) > 3072) pbits++;
     return pbits;
@@ -1070,7 +1072,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pair_rows_fused(const u64 *keys,
                         v = __hip_atomic_load(&status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                if ((v >> 62) == 0) { ticket[1] = 1; v = PF_FLAG_PRE; } // gave up: the host reports it
+                if ((v >> 62) == 0) { atomicOr(&ticket[1], 1u); v = PF_FLAG_PRE; } // gave up: the host reports it
                 const u64 is_pre = __ballot((v >> 62) == 2);
                 const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
                 u64 contrib = lane <= first ? (v & PF_VAL_MASK) : 0;
@@ -1149,14 +1151,14 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
     }
     {
         // ---- query postings grouped on the top pbits hash bits (the join needs locality, not order)
-        const int pbits = ks_join_pbits(n_t);
+        const int pbits = ix->pbits;
         const u32 n_buckets = 1u << pbits;
         const int tbits = bits_for(ix->n_targets); // pair key = qid << tbits | tid
         // a match is one 8-byte record (qid, tid, target abundance) whenever the three fit 64 bits — always, short of
         // ~10^5 x 10^5 proteins with 2^30-fold repeats — so the match sort moves keys only; else ids and abundance travel apart
         const int qbits = bits_for(q->n_seqs);
         int abits = bits_for_value(ix->max_abund);
-        const bool packed = tbits + qbits + abits <= 64 && !getenv("KS_DEBUG_UNPACKED_PAIRS");
+        const bool packed = tbits + qbits + abits <= 64 && !ks_dbg(ctx, KS_DBG_UNPACKED_PAIRS);
         if (!packed) abits = 0;
         const u32 pfxK = ks_join_prefix_mul(pbits, ks_max_hash(ix->params.scaled));
         SE_CHECK(ks_alloc(ctx, &dir_q, (size_t)2 * n_buckets + 2));
@@ -1233,11 +1235,11 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             {
                 const u64 per_bucket = n_q / n_buckets, round = (u64)JN_THREADS * JN_E;
                 const u64 reservations = (u64)n_buckets * ((per_bucket + round - 1) / round ? (per_bucket + round - 1) / round : 1);
-                n_segs = (ix->fp_layout && reservations >= 8192 && n_buckets >= JN_SEGS && !getenv("KS_DEBUG_ONE_CURSOR")) ? JN_SEGS : 1;
-                if (ix->fp_layout && getenv("KS_DEBUG_JOIN_SEGS") && n_buckets >= JN_SEGS) n_segs = JN_SEGS; // (tests: small inputs through the segmented path)
+                n_segs = (ix->fp_layout && reservations >= 8192 && n_buckets >= JN_SEGS && !ks_dbg(ctx, KS_DBG_ONE_CURSOR)) ? JN_SEGS : 1;
+                if (ix->fp_layout && ks_dbg(ctx, KS_DBG_JOIN_SEGS) && n_buckets >= JN_SEGS) n_segs = JN_SEGS; // (tests: small inputs through the segmented path)
             }
             seg_cap = n_segs == 1 ? cap : cap / n_segs + cap / n_segs / 8 + 4096;
-            if (getenv("KS_DEBUG_JOIN_SEG_CAP")) seg_cap = strtoull(getenv("KS_DEBUG_JOIN_SEG_CAP"), nullptr, 10); // (tests: the retry)
+            if (ks_dbg(ctx, KS_DBG_JOIN_SEG_CAP)) seg_cap = strtoull(ks_dbg(ctx, KS_DBG_JOIN_SEG_CAP), nullptr, 10); // (tests: the retry)
             for (int attempt = 0; attempt < 2; attempt++) {
                 SE_CHECK(ks_alloc(ctx, &pk0, (size_t)(seg_cap * n_segs)));
                 if (!packed) SE_CHECK(ks_alloc(ctx, &pv0, (size_t)(seg_cap * n_segs)));
@@ -1245,7 +1247,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                     SE_HIP(hipMemset2DAsync(cursor, (size_t)JN_CUR_STRIDE * sizeof(u64), 0, sizeof(u64), JN_SEGS, ctx->stream));
                 ks_timer_begin(ctx, "join_buckets");
                 // (few query postings per bucket: the table kernel; KS_DEBUG_JOIN_SPARSE = 0 / 1 forces the choice in the tests)
-                const bool sparse = ix->fp_layout && (getenv("KS_DEBUG_JOIN_SPARSE") ? atoi(getenv("KS_DEBUG_JOIN_SPARSE")) != 0
+                const bool sparse = ix->fp_layout && (ks_dbg(ctx, KS_DBG_JOIN_SPARSE) ? atoi(ks_dbg(ctx, KS_DBG_JOIN_SPARSE)) != 0
                                                                                      : n_q / n_buckets <= (u64)JS_QCAP * 3 / 4);
                 if (sparse)
                     hipLaunchKernelGGL(k_join_sparse, dim3(n_buckets), dim3(JS_THREADS), 0, ctx->stream, (const u64 *)qk,
@@ -1343,7 +1345,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         }
         // run-length reduce: one fused pass for packed records (k_pair_rows_fused); heads + scan + reduce when the
         // abundances travel apart (ids + abundance wider than 64 bits)
-        const bool fused = packed && !getenv("KS_DEBUG_UNFUSED_ROWS");
+        const bool fused = packed && !ks_dbg(ctx, KS_DBG_UNFUSED_ROWS);
         const u32 gp = (u32)((n_pairs + 255) / 256);
         const u32 pf_tiles = (u32)((n_pairs + PF_TILE - 1) / PF_TILE);
         u32 *nrows_dev = nullptr;
@@ -1364,7 +1366,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         // their size from the previous search of this context (+ 25 %) and the count is read with the final
         // synchronisation; a search that produced more rows than that repeats the (cheap) reduce with exact arrays.
         u64 rows_cap = n_pairs;
-        if (ctx->rows_hint && ctx->rows_hint < rows_cap && !getenv("KS_DEBUG_NO_ROWS_HINT")) rows_cap = ctx->rows_hint;
+        if (ctx->rows_hint && ctx->rows_hint < rows_cap && !ks_dbg(ctx, KS_DBG_NO_ROWS_HINT)) rows_cap = ctx->rows_hint;
         u32 n_rows = 0;
         for (int attempt = 0; attempt < 3; attempt++) { // (repeats: more rows than the guess; a look-back that gave up)
             SE_CHECK(ks_alloc(ctx, &H->d_qid, (size_t)rows_cap)); SE_CHECK(ks_alloc(ctx, &H->d_tid, (size_t)rows_cap));
@@ -1376,7 +1378,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 ks_timer_begin(ctx, "pair_rows");
                 hipLaunchKernelGGL(k_pair_rows_fused, dim3(pf_tiles), dim3(PF_THREADS), 0, ctx->stream, (const u64 *)pk, n_pairs, H->d_qid, H->d_tid,
                                    H->d_isect, (unsigned long long *)H->d_nw, tbits, abits, (u32)rows_cap, pf_status, pf_ticket, nrows_dev,
-                                   (ctx->rows_use_ticket || getenv("KS_DEBUG_ROWS_TICKET")) ? 1 : 0);
+                                   (ctx->rows_use_ticket || ks_dbg(ctx, KS_DBG_ROWS_TICKET)) ? 1 : 0);
                 ks_timer_end(ctx);
                 SE_HIP(hipMemcpyAsync(ctx->h_pin + 1, pf_ticket, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream)); // ticket pair + row count
             } else {
@@ -1391,7 +1393,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             SE_HIP(hipStreamSynchronize(ctx->stream));
             SE_CHECK(ks_scan_status_check(ctx));
             bool gave_up = fused && ((u32 *)(ctx->h_pin + 1))[1] != 0;
-            if (fused && getenv("KS_DEBUG_FORCE_ROWS_TICKET_RETRY") && !ctx->rows_use_ticket) gave_up = true; // (tests)
+            if (fused && ks_dbg(ctx, KS_DBG_FORCE_ROWS_TICKET_RETRY) && !ctx->rows_use_ticket) gave_up = true; // (tests)
             if (gave_up) {
                 if (ctx->rows_use_ticket || attempt == 2) { st = ks_fail(ctx, KS_ERR_HIP, "search: row look-back gave up waiting for a predecessor tile"); goto done; }
                 ctx->rows_use_ticket = true; // dispatch order did not hold here: tickets from now on

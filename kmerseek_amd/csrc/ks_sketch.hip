@@ -87,6 +87,7 @@ struct sk_args {
     u32 c_div, c_rcp; // compacting variant: bucket space is positions / c_div (c_rcp = ceil(2^32 / c_div))
     u64 out_cap;   // capacity of out_hash / out_abund (MODE 0): writes beyond it are dropped and the host repeats larger
     u32 use_ticket; // tile ids from the atomic ticket (1) or from blockIdx.x (0)
+    u32 debug_skip_tile; // diagnostics (KS_DEBUG_LOOKBACK_SKIP): this tile never publishes — its successors' spins really expire
     u32 le_cap;    // a sequence whose LOCAL end lies beyond this is not this launch's business
     u32 max_len_tile; // ... nor is one longer than this (packed tiles: PK_MAX_LEN, so that "long" means the same everywhere)
     const u32 *seq_list; // MODE 0: tile_first[n_tiles + 1] (tile -> first sequence); MODE 1: the medium sequences
@@ -769,7 +770,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     const u32 ne = MODE == 0 ? (ext_n < 4 ? ext_n : 4) : 0;
     u64 agg = n_distinct;
     for (u32 e = 0; e < ne; e++) agg += ext_cnt[e];
-    if (MODE == 0 && tid == 0)
+    if (MODE == 0 && tid == 0 && tile != A.debug_skip_tile)
         __hip_atomic_store(&A.tile_status[tile], (tile == 0 ? SK_FLAG_PRE : SK_FLAG_AGG) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     SK_STAMP_AT(5);
@@ -1052,7 +1053,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                 idx -= 64 * SK_LB_WAVES;
                 __syncthreads(); // (lb_sum / lb_pre are written again)
             }
-            if (tid == 0)
+            if (tid == 0 && tile != A.debug_skip_tile)
                 __hip_atomic_store(&A.tile_status[tile], SK_FLAG_PRE | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             __syncthreads();
@@ -1463,7 +1464,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_kmerpos_tiles(kp_args A) {
                         v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                if ((v >> 62) == 0) { A.ticket[1] = 1; v = SK_FLAG_PRE; }
+                if ((v >> 62) == 0) { atomicOr(&A.ticket[1], 1u); v = SK_FLAG_PRE; }
                 const u64 is_pre = __ballot((v >> 62) == 2);
                 const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
                 u64 contrib = tid <= first ? (v & SK_VAL_MASK) : 0;
@@ -1550,7 +1551,7 @@ int ks_kmerpos_tiles_launch(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32
             break;
         }
         bool gave_up = ((u32 *)(ctx->h_pin + 1))[1] != 0;
-        if (!use_ticket && getenv("KS_DEBUG_FORCE_TICKET_RETRY")) gave_up = true; // exercises the repeat
+        if (!use_ticket && ks_dbg(ctx, KS_DBG_FORCE_TICKET_RETRY)) gave_up = true; // exercises the repeat
         if (!gave_up) { *n_out = ctx->h_pin[0]; break; }
         if (use_ticket) { st = ks_fail(ctx, KS_ERR_HIP, "k-mer positions: look-back gave up waiting for a predecessor tile"); break; }
         ctx->sketch_use_ticket = true; // dispatch order did not hold here: tickets from now on (shared with the sketch tiles)
@@ -1637,7 +1638,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     u64 n_med = 0, n_long = 0, out_cap = 0; // (with a plan from max_seq_len: upper bounds, the true counts stay on the device)
     u64 win_bound = 0;                      // k-mer windows of the batch, or an upper bound (n_res) until the final read
     u32 real_max = 0, tile_R = sk_r_cand_host[0];
-    const bool planned = max_seq_len > 0 && !getenv("KS_DEBUG_NO_PLAN");
+    const bool planned = max_seq_len > 0 && !ks_dbg(ctx, KS_DBG_NO_PLAN);
     u32 *pk_tiles = nullptr, *pk_cnt = nullptr, *d_ntiles = nullptr;
     u64 *tile_g0 = nullptr;
     u64 pk_n_tiles = 0; // packed plan: tiles of the batch (read back with the statistics, or an upper bound: pk_bound)
@@ -1647,20 +1648,20 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     // once.  (Worth ~20 us per call: small batches; a 1M-protein launch would not notice either way.)
     u64 pk_bound = 0;
     // compacting variant: bucket space = positions / c_div, span = residues per shared tile (see k_sketch_tiles<0, 1>)
-    const bool compact = (variant & 1) && p->scaled >= 2 && !getenv("KS_DEBUG_NO_COMPACT");
+    const bool compact = (variant & 1) && p->scaled >= 2 && !ks_dbg(ctx, KS_DBG_NO_COMPACT);
     const u32 c_div = compact ? (p->scaled < 64 ? p->scaled : 64u) : 1u;
     u32 span = SK_TILE;
     if (compact) {
         u64 sp = (u64)c_div * 3840; // span / c_div + SK_SEQ_CAP + 1 < SK_TILE buckets
         if (sp > 8ull * SK_TILE) sp = 8ull * SK_TILE;
         span = (u32)(sp / 512 * 512);
-        if (const char *f = getenv("KS_DEBUG_SPAN")) { // tuning aid
+        if (const char *f = ks_dbg(ctx, KS_DBG_SPAN)) { // tuning aid
             const u32 v = (u32)atoi(f) / 512 * 512;
             if (v >= SK_TILE && v <= sp) span = v;
         }
     }
     // packed tiles (whole sequences packed greedily into each tile, see k_pack_walk) for the plain variant
-    const bool packed = !compact && !getenv("KS_DEBUG_NO_PACK");
+    const bool packed = !compact && !ks_dbg(ctx, KS_DBG_NO_PACK);
     // (the walk of a chunk is a serial chain, ~0.5 us per tile: small batches take shorter chunks — more waves, shorter
     // chains — at the price of one partly filled tile per chunk)
     const u32 pk_chunk = n_seqs >= 262144 ? PK_CHUNK : (n_seqs >= 32768 ? 256u : 64u);
@@ -1706,7 +1707,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
         }
-        if (packed && planned && max_seq_len <= PK_MAX_LEN && !getenv("KS_DEBUG_PLAN_SYNC")) {
+        if (packed && planned && max_seq_len <= PK_MAX_LEN && !ks_dbg(ctx, KS_DBG_PLAN_SYNC)) {
             const u64 b = n_res / (SK_MED_MAX - 15 - max_seq_len + 1) + pk_chunks + 1;
             const u64 typical = n_res / 3800 + pk_chunks + 1;
             if (b <= 2 * typical + 256 && b <= n_seqs) pk_bound = b;
@@ -1735,7 +1736,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                                     20.0 * (double)ctx->h_pin[4 + SK_NR + c];
                 if (c == 0 || cost < best) { best = cost; tile_R = cand.r[c]; n_med = ctx->h_pin[4 + c]; n_long = ctx->h_pin[4 + SK_NR + c]; }
             }
-            if (const char *force = getenv("KS_DEBUG_TILE_R")) // tuning aid: one of sk_r_cand (counted strides only)
+            if (const char *force = ks_dbg(ctx, KS_DBG_TILE_R)) // tuning aid: one of sk_r_cand (counted strides only)
                 for (int c = 0; c < SK_NR - 2; c++)
                     if (atoi(force) == (int)sk_r_cand_host[c]) { tile_R = cand.r[c]; n_med = ctx->h_pin[4 + c]; n_long = ctx->h_pin[4 + SK_NR + c]; }
             if (packed) { tile_R = 0; n_med = 0; n_long = ctx->h_pin[2]; } // nothing is deferred for its position
@@ -1764,7 +1765,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             const u64 want = S->n_windows / p->scaled + S->n_windows / (4ull * p->scaled) + 65536;
             if (want < out_cap) out_cap = want;
         }
-        if (const char *f = getenv("KS_DEBUG_OUT_CAP")) // exercises the repeat on small inputs
+        if (const char *f = ks_dbg(ctx, KS_DBG_OUT_CAP)) // exercises the repeat on small inputs
             if (!(variant & 2) && strtoull(f, nullptr, 10) < out_cap) out_cap = strtoull(f, nullptr, 10);
         SK_CHECK(ks_alloc(ctx, &S->d_hashes, (size_t)out_cap));
         SK_CHECK(ks_alloc(ctx, &S->d_abunds, (size_t)out_cap));
@@ -1873,6 +1874,8 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         }
         for (int attempt = 0; attempt < 2; attempt++) {
             A.use_ticket = (ctx->sketch_use_ticket || attempt == 1) ? 1u : 0u;
+            A.debug_skip_tile = 0xffffffffu;
+            if (!A.use_ticket && ks_dbg(ctx, KS_DBG_LOOKBACK_SKIP)) A.debug_skip_tile = (u32)atoi(ks_dbg(ctx, KS_DBG_LOOKBACK_SKIP)); // (tests: a real expired spin)
             if (attempt == 1) { // the dispatch-order launch gave up a look-back: start the tiles over, ids by ticket
                 ctx->sketch_use_ticket = true;
                 ctx->sketch_ticket_fallbacks++;
@@ -1917,7 +1920,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, SK_CTL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
             SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
             u32 &status_w = ((u32 *)(ctx->h_pin + 20))[1];
-            if (attempt == 0 && !A.use_ticket && getenv("KS_DEBUG_FORCE_TICKET_RETRY")) status_w |= 1u; // exercises the repeat
+            if (attempt == 0 && !A.use_ticket && ks_dbg(ctx, KS_DBG_FORCE_TICKET_RETRY)) status_w |= 1u; // exercises the repeat
             if (!(status_w & 1u) || A.use_ticket) break;
         }
         S->n_hashes = ctx->h_pin[23];

@@ -77,11 +77,34 @@ def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class _FollowDebugEnv:
+    """Library proxy of a diagnostic context: re-reads the KS_DEBUG_* variables before every call (the library itself reads
+    them only when a context is created).  The tests use it to force the rarely taken paths on one context."""
+
+    def __init__(self, L, ctx):
+        self._L, self._ctx = L, ctx
+
+    def __getattr__(self, name):
+        f = getattr(self._L, name)
+        if not name.startswith("ks_") or name in ("ks_ctx_create", "ks_ctx_destroy", "ks_ctx_reload_debug_env", "ks_last_error",
+                                                    "ks_status_string"):
+            return f
+
+        def call(*a):
+            if self._ctx._h:
+                self._L.ks_ctx_reload_debug_env(self._ctx._h)
+            return f(*a)
+        return call
+
+
 class Context:
     """One HIP device + stream + workspace (ks_ctx).  Not thread-safe: one per host thread."""
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, follow_debug_env: bool = False):
         self._L = _lib.load()
+        self._h = None
+        if follow_debug_env:
+            self._L = _FollowDebugEnv(self._L, self)
         h = C.c_void_p()
         st = self._L.ks_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
         if st != _lib.KS_OK:
@@ -155,6 +178,10 @@ class Context:
         """Transport words -> columns, all device pointers (ks_hits_unpack64_device): the receiving side of the exchange."""
         self._check(self._L.ks_hits_unpack64_device(self._h, C.c_void_p(d_packed), n, qbits, tbits, C.c_void_p(d_qid), C.c_void_p(d_tid),
                                                     C.c_void_p(d_isect), C.c_void_p(d_nw)))
+
+    def reload_debug_env(self):
+        """Re-read the KS_DEBUG_* variables (diagnostics: the library reads them only when a context is created)."""
+        self._check(self._L.ks_ctx_reload_debug_env(self._h))
 
     def search_stats(self) -> Dict[str, int]:
         """Repeats ks_search needed so far on this context (see ks_ctx_search_stats)."""
@@ -312,11 +339,26 @@ class _Owned:
 
     def __init__(self, ctx: Context, handle):
         self._ctx, self._h = ctx, handle
+        self._pins, self._free_pending = 0, False
 
     def free(self):
+        """Release the device object now — or, while views of its device arrays are alive (pin / unpin: the world-size-1
+        hit exchange hands out torch views instead of copies), as soon as the last of them is gone."""
+        if getattr(self, "_pins", 0) > 0:
+            self._free_pending = True
+            return
         if getattr(self, "_h", None) and self._ctx._h:
             getattr(self._ctx._L, self._free)(self._h)
         self._h = None
+
+    def pin(self):
+        self._pins += 1
+
+    def unpin(self):
+        self._pins -= 1
+        if self._pins == 0 and self._free_pending:
+            self._free_pending = False
+            self.free()
 
     def __del__(self):
         try:

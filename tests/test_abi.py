@@ -111,6 +111,32 @@ def test_no_device_fails_loudly(lib):
     assert e.value.status == _lib.KS_ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
 
 
+def test_nothing_throws_across_the_boundary(lib):
+    """include/kmerseek_amd.h: every entry point that can allocate runs behind an exception guard — std::bad_alloc comes out
+    as KS_ERR_OOM, anything else as KS_ERR_HIP, never as std::terminate (errors are values: src/rust/errors.rs:8-24)."""
+    assert lib.ks_debug_guard_selftest(b"nothing") == _lib.KS_OK
+    assert lib.ks_debug_guard_selftest(b"bad_alloc") in (_lib.KS_ERR_OOM, _lib.KS_ERR_HIP)  # (bad_alloc, or length_error from the reservation)
+    assert lib.ks_debug_guard_selftest(b"runtime") == _lib.KS_ERR_HIP
+    assert lib.ks_debug_guard_selftest(b"other") == _lib.KS_ERR_HIP
+
+
+def test_every_entry_point_with_a_context_is_guarded():
+    """Source check: an extern "C" int function that takes a ks_ctx and spans more than one statement hands its body to ks_guard."""
+    import re
+    csrc = os.path.join(ROOT, "kmerseek_amd", "csrc")
+    unguarded = []
+    for f in ("ks_api.hip", "ks_ctx.hip", "ks_copy.hip"):
+        src = open(os.path.join(csrc, f)).read()
+        for m in re.finditer(r'^extern "C" int (\w+)\(([^)]*)\)\s*\{', src, re.M):
+            name, params = m.group(1), m.group(2)
+            if "ks_ctx *ctx" not in params or name in ("ks_ctx_reload_debug_env",):
+                continue
+            head = src[m.end():m.end() + 120]
+            if "ks_guard(" not in head:
+                unguarded.append(name)
+    assert not unguarded, unguarded
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "kmerseek_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -14,7 +14,7 @@ from oracle import oracle
 
 @pytest.fixture(scope="module")
 def ctx():
-    c = ks.Context(0)
+    c = ks.Context(0, follow_debug_env=True)
     yield c
     c.close()
 
@@ -133,6 +133,19 @@ def test_dist_layer_single_rank_gpu(ctx):
     assert np.array_equal(got[3].cpu().numpy().view(np.uint64), want[3])
     ptrs = h.device_ptrs()
     assert all(p != 0 for p in ptrs)
+    # one rank, no id shift: the columns themselves come back as torch views (no D2D copy), and they keep the hit list alive
+    views = ksd.all_gather_hits_device(h, device=dev)
+    assert views[0].data_ptr() == ptrs[0] and views[3].data_ptr() == ptrs[3]
+    for g, w_ in zip(views, want):
+        assert np.array_equal(g.cpu().numpy().view(w_.dtype), w_)
+    # an id that does not fit its field is not packed into its neighbour: the escape count says "take the other exchange"
+    n = h.count
+    small = torch.zeros(n + 1 + 2 * 64, dtype=torch.int64, device=dev)
+    torch.cuda.current_stream(dev).synchronize()
+    sb = small.data_ptr()
+    h.pack64_to_device(sb, sb + 8 * (n + 1), sb + 8 * (n + 1) + 4 * 64, sb + 8 * (n + 1 + 64), sb + 8 * n, 64, 4, 4, qid_base=7, tid_base=9)
+    ctx.synchronize()
+    assert (int(small[n]) & 0xffffffff) > 64
     # transport words of the multi-GPU exchange (8 instead of 20 bytes per row): packed on the device, unpacked as
     # dist._gather_packed does, rows with wide values through the escape list
     n = h.count
@@ -141,6 +154,7 @@ def test_dist_layer_single_rank_gpu(ctx):
         vmax = (1 << v) - 1
         esc_cap = 4096
         buf = torch.zeros(n + 1 + 2 * esc_cap, dtype=torch.int64, device=dev)
+        torch.cuda.current_stream(dev).synchronize()  # the fill ran on torch's stream, the pack runs on the context's own
         base = buf.data_ptr()
         h.pack64_to_device(base, base + 8 * (n + 1), base + 8 * (n + 1) + 4 * esc_cap, base + 8 * (n + 1 + esc_cap), base + 8 * n,
                            esc_cap, qbits, tbits, qid_base=7, tid_base=9)
@@ -171,7 +185,8 @@ def test_dist_layer_single_rank_gpu(ctx):
     ksd._dist = lambda: _TwoRanks
     try:
         for qbits, tbits in ((12, 12), (24, 24)):
-            out = ksd._gather_packed(h, True, n, [n, n], 7, 9, qbits, tbits, dev, ctx.synchronize)
+            out = ksd._gather_packed(h, True, n, [n, n], 7, 9, qbits, tbits, dev, ctx.synchronize,
+                                         lambda: torch.cuda.current_stream(dev).synchronize())
             assert out is not None
             for col, w_, add, dt in zip(out, want, (7, 9, 0, 0), (np.uint32, np.uint32, np.uint32, np.uint64)):
                 got_col = col.cpu().numpy().view(dt)

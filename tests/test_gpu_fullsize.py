@@ -17,7 +17,7 @@ from oracle import oracle
 
 @pytest.fixture(scope="module")
 def ctx():
-    c = ks.Context(0)
+    c = ks.Context(0, follow_debug_env=True)
     yield c
     c.close()
 

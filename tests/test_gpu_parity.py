@@ -16,7 +16,7 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 @pytest.fixture(scope="module")
 def ctx():
-    c = ks.Context(0)
+    c = ks.Context(0, follow_debug_env=True)
     yield c
     c.close()
 
@@ -515,7 +515,7 @@ def test_sketch_repeats_with_ticket_ids_when_a_lookback_gives_up(monkeypatch):
     seqs = [bytes(q_res[int(q_off[i]):int(q_off[i + 1])]) for i in range(5000)]
     q_res, q_off = ks.pack(seqs[:100] + extra[:3] + seqs[100:] + extra[3:])
     want = oracle.sketch_batch(q_res, q_off, 10, 1, "protein", n_threads=8)
-    ctx = ks.Context(0)
+    ctx = ks.Context(0, follow_debug_env=True)
     try:
         T = ctx.sketch_batch(t_res, t_off, 10, 1, "protein")
         ix = ctx.index_build(T)
@@ -536,7 +536,7 @@ def test_sketch_repeats_with_ticket_ids_when_a_lookback_gives_up(monkeypatch):
     finally:
         ctx.close()
     # the k-mer position tiles share the scheme: dispatch-order ids, forced repeat with tickets, tickets from then on
-    ctx = ks.Context(0)
+    ctx = ks.Context(0, follow_debug_env=True)
     try:
         a = ctx.kmer_positions(q_res, q_off, 10, 1, "protein")
         assert ctx.sketch_stats()["ticket_fallbacks"] == 0
@@ -550,6 +550,33 @@ def test_sketch_repeats_with_ticket_ids_when_a_lookback_gives_up(monkeypatch):
         assert len(a[0]) == int((np.maximum((q_off[1:] - q_off[:-1]).astype(np.int64) - 9, 0)).sum())
     finally:
         ctx.close()
+
+
+def test_a_really_expired_lookback_spin_is_repaired_by_the_ticket_repeat(monkeypatch):
+    """the forced retries above never run with a spin that really expired.  Here one tile of the first attempt never
+    publishes (KS_DEBUG_LOOKBACK_SKIP): its successors spin out (~2 s), the launch flags it, partially written outputs and
+    posting cursors and all, and the ticket repeat must deliver exact sketches and postings."""
+    t_res, t_off = synth.proteome(3000, stream=410)
+    q_res, q_off = synth.queries(2500, t_res, t_off, stream=411)
+    want = oracle.sketch_batch(q_res, q_off, 10, 1, "protein", n_threads=8)
+    c = ks.Context(0, follow_debug_env=True)
+    try:
+        T = c.sketch_batch(t_res, t_off, 10, 1, "protein")
+        ix = c.index_build(T)
+        ref_hits = c.search(ix, c.sketch_batch(q_res, q_off, 10, 1, "protein")).to_host()
+        d_res, d_off = c.to_device(q_res), c.to_device(q_off)
+        monkeypatch.setenv("KS_DEBUG_LOOKBACK_SKIP", "3")
+        Q = c.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
+        monkeypatch.delenv("KS_DEBUG_LOOKBACK_SKIP")
+        st = c.sketch_stats()
+        assert st["ticket_fallbacks"] == 1 and st["uses_ticket"] == 1
+        for g, w in zip(Q.to_host(), want):
+            assert np.array_equal(g, w)
+        assert Q.has_postings
+        for g, w in zip(c.search(ix, Q).to_host(), ref_hits):
+            assert np.array_equal(g, w)
+    finally:
+        c.close()
 
 
 def test_max_seq_len_plan_equals_measured_plan(ctx):
@@ -745,7 +772,7 @@ def test_join_fingerprints_segments_and_retry_are_exact(ctx, monkeypatch, k, sca
 def test_row_pass_repeats_with_ticket_ids_when_a_lookback_gives_up(monkeypatch):
     """k_pair_rows_fused takes its tile ids from blockIdx.x (dispatch order); a launch whose look-back gave up is repeated with
     ticket-ordered tiles and the context keeps tickets from then on.  Same rows either way."""
-    c = ks.Context(0)
+    c = ks.Context(0, follow_debug_env=True)
     try:
         t_res, t_off = synth.proteome(3000, stream=410)
         q_res, q_off = synth.queries(2500, t_res, t_off, stream=411)
@@ -798,3 +825,38 @@ def test_join_kernels_agree_on_heavily_repeated_hashes(ctx, monkeypatch):
         hits.free(); ix.free()
         for kk in env:
             monkeypatch.delenv(kk)
+
+
+def test_failures_inside_the_library_come_back_as_status_codes(monkeypatch):
+    """an exception inside an entry point (forced: KS_DEBUG_THROW) and a device pool that cannot grow
+    (forced: KS_DEBUG_POOL_CAP) are status codes at the boundary — not a SIGABRT — and the context keeps working."""
+    res, offs = synth.proteome(2000, stream=77)
+    want = oracle.sketch_batch(res, offs, 10, 1, "protein", n_threads=4)
+    c = ks.Context(0, follow_debug_env=True)
+    try:
+        for what, status in (("bad_alloc", ks._lib.KS_ERR_OOM), ("runtime", ks._lib.KS_ERR_HIP), ("other", ks._lib.KS_ERR_HIP)):
+            monkeypatch.setenv("KS_DEBUG_THROW", what)
+            with pytest.raises(ks.KmerseekError) as e:
+                c.sketch_batch(res, offs, 10, 1, "protein")
+            assert e.value.status == status, (what, e.value.status, str(e.value))
+            monkeypatch.delenv("KS_DEBUG_THROW")
+        monkeypatch.setenv("KS_DEBUG_POOL_CAP", str(256 * 1024))  # far less than the batch needs
+        with pytest.raises(ks.KmerseekError) as e:
+            c.sketch_batch(res, offs, 10, 1, "protein")
+        assert e.value.status == ks._lib.KS_ERR_OOM and "pool cap" in str(e.value)
+        monkeypatch.delenv("KS_DEBUG_POOL_CAP")
+        S = c.sketch_batch(res, offs, 10, 1, "protein")  # the same context, afterwards: exact
+        for g, w in zip(S.to_host(), want):
+            assert np.array_equal(g, w)
+        T = c.index_build(S)
+        monkeypatch.setenv("KS_DEBUG_POOL_CAP", str(c.pool_stats()["bytes_held"]))  # no growth from here on
+        try:
+            H = c.search(T, S)  # may or may not fit what the pool already holds: either exact or a clean KS_ERR_OOM
+            assert H.count >= 2000
+        except ks.KmerseekError as e2:
+            assert e2.status == ks._lib.KS_ERR_OOM
+        monkeypatch.delenv("KS_DEBUG_POOL_CAP")
+        H = c.search(T, S)
+        assert H.count >= 2000
+    finally:
+        c.close()

@@ -20,7 +20,7 @@ PARAMS = [(24, 5, "hp"), (16, 5, "dayhoff"), (10, 1, "protein"), (7, 1, "hp")]
 
 @pytest.fixture(scope="module")
 def ctx():
-    c = ks.Context(0)
+    c = ks.Context(0, follow_debug_env=True)
     yield c
     c.close()
 

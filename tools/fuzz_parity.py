@@ -51,7 +51,7 @@ def draw_batch(rng):
 def run(cases: int, seed: int) -> int:
     """Runs `cases` random cases; prints one line per failure; returns the number of failures."""
     rng = np.random.default_rng(seed)
-    ctx = ks.Context(0)
+    ctx = ks.Context(0, follow_debug_env=True)
     bad = 0
     for case in range(cases):
         k = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 10, 15, 16, 17, 21, 24, 31, 32, 33, 48, 64, 100, 128]))
@@ -116,7 +116,7 @@ def run_big(cases: int, seed: int) -> int:
     the pairwise oracle search is quadratic."""
     from kmerseek_amd import synth
     rng = np.random.default_rng(seed)
-    ctx = ks.Context(0)
+    ctx = ks.Context(0, follow_debug_env=True)
     bad = 0
     for case in range(cases):
         k = int(rng.choice([5, 7, 10, 16, 21, 24, 32]))
