@@ -268,7 +268,7 @@ void ProteomeIndex::store_signatures_batch(const std::vector<ProteinSignature> &
 
 void ProteomeIndex::process_fasta(const std::string &fasta_path, uint32_t progress_interval, size_t batch_size) {
     if (progress_interval > 0) printf("Reading FASTA file with automatic compression detection and parallel processing...\n");
-    // plain / gzip / zstd by magic number (ks_input.h), as needletail's parse_fastx_file does (index.rs:907-961)
+    // plain / gzip / zstd / bzip2 / xz by magic number (ks_input.h), as needletail's parse_fastx_file does (index.rs:907-961)
     std::string oerr;
     std::unique_ptr<KsInput> in(KsInput::open(fasta_path.c_str(), oerr));
     if (!in) throw IndexError(IndexError::ParseError, "Parse error: " + oerr);

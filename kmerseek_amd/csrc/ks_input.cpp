@@ -128,6 +128,154 @@ class ZstdInput : public KsInput {
     bool file_eof_ = false;
 };
 
+// ---- libbz2 and liblzma, bound at run time like libzstd (needletail's default `compression` feature reads bzip2 and xz
+// as well: src/rust/index.rs:920 parse_fastx_file).  Stream structs as bzlib.h / lzma/base.h declare them (stable ABIs).
+struct bz_stream_t {
+    char *next_in; unsigned avail_in, total_in_lo32, total_in_hi32;
+    char *next_out; unsigned avail_out, total_out_lo32, total_out_hi32;
+    void *state;
+    void *(*bzalloc)(void *, int, int); void (*bzfree)(void *, void *); void *opaque;
+};
+struct Bz2Api {
+    void *lib = nullptr;
+    int (*init)(bz_stream_t *, int, int) = nullptr;
+    int (*run)(bz_stream_t *) = nullptr;
+    int (*end)(bz_stream_t *) = nullptr;
+    bool ok = false;
+};
+const Bz2Api &bz2_api() {
+    static Bz2Api api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        api.init = (int (*)(bz_stream_t *, int, int))dlsym(api.lib, "BZ2_bzDecompressInit");
+        api.run = (int (*)(bz_stream_t *))dlsym(api.lib, "BZ2_bzDecompress");
+        api.end = (int (*)(bz_stream_t *))dlsym(api.lib, "BZ2_bzDecompressEnd");
+        api.ok = api.init && api.run && api.end;
+    });
+    return api;
+}
+
+class Bz2Input : public KsInput {
+  public:
+    explicit Bz2Input(FILE *f) : f_(f), in_(1 << 20) { memset(&s_, 0, sizeof s_); live_ = bz2_api().init(&s_, 0, 0) == 0; }
+    ~Bz2Input() override {
+        if (live_) bz2_api().end(&s_);
+        fclose(f_);
+    }
+    long read(void *dst, size_t cap) override {
+        const Bz2Api &z = bz2_api();
+        if (cap > 0x40000000u) cap = 0x40000000u;
+        s_.next_out = (char *)dst; s_.avail_out = (unsigned)cap;
+        while (s_.avail_out == cap) {
+            if (s_.avail_in == 0 && !file_eof_) {
+                const size_t n = fread(in_.data(), 1, in_.size(), f_);
+                if (n == 0) {
+                    if (ferror(f_)) { err_ = std::string("read failed: ") + strerror(errno); return -1; }
+                    file_eof_ = true;
+                }
+                s_.next_in = (char *)in_.data(); s_.avail_in = (unsigned)n;
+            }
+            if (!live_) { // between streams: more input starts another one (concatenated archives are one file)
+                if (s_.avail_in == 0 && file_eof_) return 0;
+                if (z.init(&s_, 0, 0) != 0) { err_ = "BZ2_bzDecompressInit failed"; return -1; }
+                live_ = true;
+            }
+            if (s_.avail_in == 0 && file_eof_) { err_ = "bzip2 stream is truncated (unexpected end of file)"; return -1; }
+            const int r = z.run(&s_);
+            if (r == 4) { z.end(&s_); live_ = false; } // BZ_STREAM_END
+            else if (r != 0) { err_ = "bzip2 stream is corrupt (code " + std::to_string(r) + ")"; return -1; }
+        }
+        return (long)(cap - s_.avail_out);
+    }
+    const char *format() const override { return "bzip2"; }
+
+  private:
+    FILE *f_;
+    bz_stream_t s_;
+    std::vector<unsigned char> in_;
+    bool live_ = false, file_eof_ = false;
+};
+
+struct lzma_stream_t {
+    const uint8_t *next_in; size_t avail_in; uint64_t total_in;
+    uint8_t *next_out; size_t avail_out; uint64_t total_out;
+    const void *allocator; void *internal;
+    void *reserved_ptr1, *reserved_ptr2, *reserved_ptr3, *reserved_ptr4;
+    uint64_t reserved_int1, reserved_int2; size_t reserved_int3, reserved_int4;
+    int reserved_enum1, reserved_enum2;
+};
+struct XzApi {
+    void *lib = nullptr;
+    int (*decoder)(lzma_stream_t *, uint64_t, uint32_t) = nullptr;
+    int (*code)(lzma_stream_t *, int) = nullptr;
+    void (*end)(lzma_stream_t *) = nullptr;
+    bool ok = false;
+};
+const XzApi &xz_api() {
+    static XzApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"liblzma.so.5", "liblzma.so"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        api.decoder = (int (*)(lzma_stream_t *, uint64_t, uint32_t))dlsym(api.lib, "lzma_stream_decoder");
+        api.code = (int (*)(lzma_stream_t *, int))dlsym(api.lib, "lzma_code");
+        api.end = (void (*)(lzma_stream_t *))dlsym(api.lib, "lzma_end");
+        api.ok = api.decoder && api.code && api.end;
+    });
+    return api;
+}
+
+class XzInput : public KsInput {
+  public:
+    explicit XzInput(FILE *f) : f_(f), in_(1 << 20) {
+        memset(&s_, 0, sizeof s_); // LZMA_STREAM_INIT
+        live_ = xz_api().decoder(&s_, ~0ULL, 0x08 /* LZMA_CONCATENATED */) == 0;
+    }
+    ~XzInput() override {
+        if (live_) xz_api().end(&s_);
+        fclose(f_);
+    }
+    long read(void *dst, size_t cap) override {
+        const XzApi &z = xz_api();
+        if (!live_) { err_ = "lzma_stream_decoder failed"; return -1; }
+        if (done_) return 0;
+        s_.next_out = (uint8_t *)dst; s_.avail_out = cap;
+        while (s_.avail_out == cap) {
+            if (s_.avail_in == 0 && !file_eof_) {
+                const size_t n = fread(in_.data(), 1, in_.size(), f_);
+                if (n == 0) {
+                    if (ferror(f_)) { err_ = std::string("read failed: ") + strerror(errno); return -1; }
+                    file_eof_ = true;
+                }
+                s_.next_in = in_.data(); s_.avail_in = n;
+            }
+            const int r = z.code(&s_, file_eof_ ? 3 /* LZMA_FINISH */ : 0 /* LZMA_RUN */);
+            if (r == 1) { done_ = true; break; } // LZMA_STREAM_END (with LZMA_CONCATENATED: only once the input is finished)
+            if (r == 10 || (r == 0 && file_eof_ && s_.avail_in == 0 && s_.avail_out == cap)) { // LZMA_BUF_ERROR: no progress possible
+                err_ = "xz stream is truncated (unexpected end of file)";
+                return -1;
+            }
+            if (r != 0) { err_ = "xz stream is corrupt (code " + std::to_string(r) + ")"; return -1; }
+        }
+        return (long)(cap - s_.avail_out);
+    }
+    const char *format() const override { return "xz"; }
+
+  private:
+    FILE *f_;
+    lzma_stream_t s_;
+    std::vector<unsigned char> in_;
+    bool live_ = false, file_eof_ = false, done_ = false;
+};
+
 } // namespace
 
 KsInput *KsInput::open(const char *path, std::string &err) {
@@ -135,8 +283,16 @@ KsInput *KsInput::open(const char *path, std::string &err) {
     if (!f) { err = std::string("cannot open ") + path + ": " + strerror(errno); return nullptr; }
     unsigned char m[6] = {0};
     const size_t got = fread(m, 1, 6, f);
-    if (got >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') { fclose(f); err = std::string("bzip2 input is not supported (plain, gzip or zstd only): ") + path; return nullptr; }
-    if (got >= 6 && m[0] == 0xfd && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z' && m[5] == 0) { fclose(f); err = std::string("xz input is not supported (plain, gzip or zstd only): ") + path; return nullptr; }
+    if (got >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') {
+        if (!bz2_api().ok) { fclose(f); err = std::string("bzip2 input, but libbz2.so.1.0 could not be loaded: ") + path; return nullptr; }
+        if (fseek(f, 0, SEEK_SET) != 0) { fclose(f); err = std::string("cannot rewind ") + path; return nullptr; }
+        return new Bz2Input(f);
+    }
+    if (got >= 6 && m[0] == 0xfd && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z' && m[5] == 0) {
+        if (!xz_api().ok) { fclose(f); err = std::string("xz input, but liblzma.so.5 could not be loaded: ") + path; return nullptr; }
+        if (fseek(f, 0, SEEK_SET) != 0) { fclose(f); err = std::string("cannot rewind ") + path; return nullptr; }
+        return new XzInput(f);
+    }
     if (got >= 2 && m[0] == 0x1f && m[1] == 0x8b) {
         fclose(f);
         gzFile g = gzopen(path, "rb");

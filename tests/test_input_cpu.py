@@ -1,4 +1,4 @@
-"""CPU-side checks of the host layer around the hot path (no GPU): the ingest's input layer (plain / gzip / zstd by magic
+"""CPU-side checks of the host layer around the hot path (no GPU): the ingest's input layer (plain / gzip / zstd / bzip2 / xz by magic
 number — the reference's needletail auto-detection, src/rust/index.rs:907-961, tested there at :1734-1845 with
 tests/testdata/fasta/test_compression.fasta{,.zst}), thread safety of validate_and_resolve on a cold library, the bounded
 reader of the flat index file, and the per-row parameter checks of the .sig.zip reader."""
@@ -39,6 +39,14 @@ def test_plain_gzip_zstd_decode_to_the_same_bytes(tmp_path):
     gz2.write_bytes(gzip.compress(big[:len(big) // 2]) + gzip.compress(big[len(big) // 2:]))
     got, fmt = host.decompress(gz2)
     assert got == big and fmt == "gzip"
+    # bzip2 and xz: needletail's default features read them too (the reference's process_fasta goes through it, index.rs:920)
+    import bz2, lzma
+    for data, name in ((bz2.compress(big), "bzip2"), (bz2.compress(big[:1000]) + bz2.compress(big[1000:]), "bzip2"),
+                       (lzma.compress(big), "xz"), (lzma.compress(big[:1000]) + lzma.compress(big[1000:]), "xz")):
+        f = tmp_path / ("big." + name)
+        f.write_bytes(data)
+        got, fmt = host.decompress(f)
+        assert got == big and fmt == name
     got, _ = host.decompress(os.path.join(GOLDEN, "bcl2_first25_uniprotkb_accession_O43236_OR_accession_2025_02_06.fasta.gz"))
     assert got == gzip.open(os.path.join(GOLDEN, "bcl2_first25_uniprotkb_accession_O43236_OR_accession_2025_02_06.fasta.gz")).read()
 
@@ -63,6 +71,27 @@ def test_truncated_archives_are_errors_not_shorter_files(tmp_path):
         with pytest.raises(host.IndexError_) as e:
             host.decompress(f)
         assert name in str(e.value)
+    import bz2, lzma
+    for data, name in ((bz2.compress(plain), "bzip2"), (lzma.compress(plain), "xz")):
+        f = tmp_path / ("cut." + name)
+        f.write_bytes(data[:len(data) * 2 // 3])
+        with pytest.raises(host.IndexError_) as e:
+            host.decompress(f)
+        assert e.value.kind == "ParseError" and name in str(e.value)
+    # a gzip file that ends exactly where a member ends is a complete (shorter) file, not a truncated one; one that ends inside
+    # its second member is an error even though the first member was whole
+    a, b = gzip.compress(plain), gzip.compress(b">b\n" + b"WYVT" * 9000 + b"\n")
+    whole = tmp_path / "member_boundary.fasta.gz"
+    whole.write_bytes(a)
+    assert host.decompress(whole) == (plain, "gzip")
+    both = tmp_path / "two_members.fasta.gz"
+    both.write_bytes(a + b)
+    assert host.decompress(both)[0] == plain + b">b\n" + b"WYVT" * 9000 + b"\n"
+    half = tmp_path / "second_member_cut.fasta.gz"
+    half.write_bytes(a + b[:len(b) // 2])
+    with pytest.raises(host.IndexError_) as e:
+        host.decompress(half)
+    assert e.value.kind == "ParseError" and "truncated" in str(e.value)
     with pytest.raises(host.IndexError_):
         host.decompress(tmp_path / "does_not_exist.fasta")
 
