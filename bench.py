@@ -270,7 +270,11 @@ def run_queries_sharded(args, env, ks, synth, ksd):
         Q.free()
         try:
             r = ctx.device_rates()
-            aux["device"] = {"name": torch.cuda.get_device_name(env.dev), "hbm_nominal_gb_per_s_from_properties": r["nominal_gb_per_s"],
+            # (hipDeviceProp_t gives memoryClockRate x memoryBusWidth; HBM3E moves 4 bits per pin and reported clock, so the
+            # double-data-rate product of the two is HALF the pin rate: both printed, the 8 TB/s constant is what frac uses)
+            aux["device"] = {"name": torch.cuda.get_device_name(env.dev),
+                             "hbm_gb_per_s_from_properties": {"clock_x_buswidth_x2": r["nominal_gb_per_s"],
+                                                              "clock_x_buswidth_x4_hbm3e_pin_rate": 2.0 * r["nominal_gb_per_s"]},
                              "d2d_copy_gb_per_s_measured": r["copy_gb_per_s"], "u64_gmul_per_s_measured": r["u64_gmul_per_s"]}
             aux["device"].update(ctx.gather_rates())  # ceiling of a table-lookup hash for the hp alphabet
         except Exception as e:  # a side line must not cost the headline
@@ -402,6 +406,37 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
+def reference_binary_probe(q_res_h, q_off_h, k, scaled, mol, n_records=20000):
+    """when the reference's own binary is at hand (`kmerseek-rust` on PATH or $KMERSEEK_RUST_BIN — the
+    crate's [[bin]], Cargo.toml:13-15), `kmerseek-rust index` is timed on a FASTA of the same proteins (src/rust/main.rs:17-46).
+    Building it here is not possible (no reference sources, registry or network on the GPU box), so `cargo` alone changes
+    nothing: the probe records what it found and otherwise stays out of the way."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.environ.get("KMERSEEK_RUST_BIN") or shutil.which("kmerseek-rust")
+    out = {"probed": True, "binary": exe, "cargo": shutil.which("cargo")}
+    if not exe:
+        out["note"] = "reference binary not present: the CPU baseline is the oracle (kind 'port')"
+        return out
+    try:
+        n = min(n_records, len(q_off_h) - 1)
+        with tempfile.TemporaryDirectory() as d:
+            fa = os.path.join(d, "sample.fasta")
+            with open(fa, "wb") as f:
+                for i in range(n):
+                    f.write(b">q%d\n" % i + bytes(q_res_h[int(q_off_h[i]):int(q_off_h[i + 1])]) + b"\n")
+            c0 = time.perf_counter()
+            r = subprocess.run([exe, "index", "--input", fa, "--output", os.path.join(d, "db"), "--ksize", str(k), "--scaled", str(scaled),
+                                "--encoding", mol], capture_output=True, timeout=600)
+            dt = time.perf_counter() - c0
+        windows = int(sum(max(int(q_off_h[i + 1] - q_off_h[i]) - k + 1, 0) for i in range(n)))
+        out.update({"rc": r.returncode, "records": n, "seconds": dt, "kmers_per_s": windows / max(dt, 1e-9) if r.returncode == 0 else None})
+    except Exception as e:  # a side line must not cost the headline
+        out["error"] = str(e)
+    return out
+
+
 def cpu_baseline(args, T, q_res_h, q_off_h, k, scaled, mol):
     """The oracle (C restatement of the reference CPU path, kind "port") on bounded samples of the same workload:
     sketch half (add_protein, signature.rs:273-282) and the second process_kmers pass (index.rs:749-786) on >= 100k query
@@ -457,7 +492,8 @@ def cpu_baseline(args, T, q_res_h, q_off_h, k, scaled, mol):
             "sketch_kmers_per_s": sk_windows / max(t_sketch, 1e-9),
             "process_kmers_pass_kmers_per_s": sk_windows / max(t_kpos, 1e-9), "process_kmers_rows": rows,
             "sketch_plus_process_kmers_kmers_per_s": 1.0 / (per_w_sketch + per_w_kpos),
-            "search_kmers_per_s": s_windows / max(t_search, 1e-9), "hits_in_sample": int(len(cq))}
+            "search_kmers_per_s": s_windows / max(t_search, 1e-9), "hits_in_sample": int(len(cq)),
+            "reference_binary": reference_binary_probe(q_res_h, q_off_h, k, scaled, mol)}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
