@@ -301,7 +301,7 @@ def run_queries_sharded(args, env, ks, synth, ksd):
         "radix_hist.qpart": 8 * n_q_hashes,
         "join_buckets": 12 * n_q_hashes + 12 * n_t_postings + 8 * n_pairs,  # postings read once + one 8-B record per match
     }
-    traffic_tab, traffic_src = load_traffic()
+    traffic_tab, traffic_src = load_traffic(profile_key(args, n_q))
 
     def roof(name):
         # the dominant kernel is bracketed by HIP events inside the timed region; the others come from the untimed pass with
@@ -378,12 +378,22 @@ def run_queries_sharded(args, env, ks, synth, ksd):
     return result, (ctx, index, T)
 
 
-def load_traffic():
+def profile_key(args, n_q_local):
+    """Name of the profiled workload (tools/gpu/profile_configs.sh) this run matches, or None: PMC traffic is per workload."""
+    w = (args.queries, args.targets, args.ksize, args.scaled, args.moltype)
+    if args.gpus != 1:
+        return None
+    return {(1_000_000, 1_000_000, 10, 1, "protein"): "c4_1m_protein_k10_s1", (10_000, 10_000, 7, 1, "protein"): "c2_10k_protein_k7_s1",
+            (100_000, 100_000, 16, 5, "dayhoff"): "c3_100k_dayhoff_k16_s5", (125_000, 1_000_000, 10, 1, "protein"): "shard_125k_of_1m"}.get(w)
+
+
+def load_traffic(key="c4_1m_protein_k10_s1"):
     """HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
     --pmc runs, gfx950 corrections applied by tools/pmc_to_traffic.py).  They are NOT measured by this run: the source
-    file, the commit it was collected at and whether the kernel sources changed since are reported beside the number."""
+    file, the commit it was collected at and whether the kernel sources changed since are reported beside the number.
+    One table per profiled workload (`per_config`); a run on any other workload reports no traffic."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(tpath):
+    if key is None or not os.path.exists(tpath):
         return {}, None
     try:
         doc = json.load(open(tpath))
@@ -393,7 +403,10 @@ def load_traffic():
     want = doc.get("kernel_sources_sha16")
     if want:
         src["kernel_sources_unchanged_since"] = (kernel_sources_sha() == want)
-    return doc.get("per_launch_bytes", {}), src
+    if "per_config" in doc:
+        src["workload"] = key
+        return (doc["per_config"].get(key) or {}).get("per_launch_bytes", {}), src
+    return (doc.get("per_launch_bytes", {}) if key == "c4_1m_protein_k10_s1" else {}), src
 
 
 def kernel_sources_sha():
@@ -541,6 +554,14 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
     for _ in range(max(args.warmup, 1)):
         stats, rows = step()
     elapsed, (stats, rows) = env.timed(step, args.steps)
+    # per-kernel table + roofline of this config (untimed pass with every launch bracketed by HIP events on the launch stream)
+    n_t_postings = index.n_postings
+    ctx.timing_reset()
+    ctx.timing_enable(1)
+    for _ in range(2):
+        step()
+    ctx.timing_enable(False)
+    timing_all = {k_: (n_ / 2, ms_ / 2) for k_, (n_, ms_) in ctx.timing().items()}
     # the gathered list is complete and holds every (qid, tid) pair once: checked once, outside the timed region, by sorting
     key = torch.sort(rows[0].to(torch.int64) << 32 | rows[1].to(torch.int64)).values
     ordered = bool((key[1:] > key[:-1]).all()) if key.numel() > 1 else True
@@ -553,7 +574,36 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
         ctx.close()
     if rank != 0:
         return None
+    ms_per_step = elapsed / args.steps * 1e3
+    # SURVEY 8(d) bytes of this rank's step: sketch of all queries + search against its index shard
+    sketch_bytes = n_res + 12 * stats[0] + 8 * n_prot
+    step_bytes = sketch_bytes + 12 * stats[0] + 12 * n_t_postings + 16 * stats[1]
+    traffic_tab, traffic_src = load_traffic("c5_200k_hp_k24_s5" if (world == 1 and (n_prot, k, scaled, mol) == (200_000, 24, 5, "hp")) else None)
+    dom = max(timing_all.items(), key=lambda kv: kv[1][1])[0] if timing_all else None
+    design = {"sketch_tiles": sketch_bytes, "bucket_scatter": 24 * stats[0], "join_buckets": 12 * stats[0] + 12 * n_t_postings + 8 * stats[2],
+              "pair_rows": 8 * stats[2] + 20 * stats[1], "msd_local": 16 * stats[2], "msd_scatter": 16 * stats[2], "msd_hist": 8 * stats[2]}
+    roofline = None
+    if dom:
+        n_l, ms = timing_all[dom]
+        b = design.get(dom)
+        avg_s = ms / max(n_l, 1) / 1e3
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": (b / n_l / avg_s / 1e9) if b and avg_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (b / n_l / avg_s / 1e9 / HBM_PEAK_GBS) if b and avg_s > 0 else None, "traffic": traffic_tab.get(dom),
+                    "traffic_source": traffic_src, "avg_launch_ms": avg_s * 1e3, "launches_per_step": n_l,
+                    "bytes_per_step_by_design": b, "duration_source": "HIP events, untimed pass after the timed region",
+                    "note": "sketch_tiles: SURVEY 8(d) bytes (n_res + 12*n_hashes + 8*n_seqs); the match-list kernels: bytes they move by design"}
+    sk = timing_all.get("sketch_tiles")
+    sketch_roofline = None
+    if sk and sk[1] > 0:
+        sketch_roofline = {"kernel": "sketch_tiles", "algorithmic_bytes_per_launch": sketch_bytes, "avg_launch_ms": sk[1] / sk[0],
+                           "achieved": sketch_bytes / (sk[1] / sk[0] / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": sketch_bytes / (sk[1] / sk[0] / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic_tab.get("sketch_tiles.compact")}
     return {
+        "roofline": roofline, "sketch_roofline": sketch_roofline,
+        "step_roofline": {"bound": "hbm", "algorithmic_bytes_per_step": step_bytes, "achieved": step_bytes / (ms_per_step / 1e3) / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_bytes / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS,
+                          "formula": "sketch (n_res + 12*N_Q + 8*n_seqs) + search (12*N_Q + 12*N_T + 16*N_hits), SURVEY 8(d)"},
+        "kernels": {name: {"launches_per_step": n, "ms_per_step": ms} for name, (n, ms) in timing_all.items()},
         "metric": "k-mers hashed+matched/sec", "value": q_windows * args.steps / elapsed, "unit": "k-mers/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",

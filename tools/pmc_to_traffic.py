@@ -35,9 +35,9 @@ def load(path, counter):
     return out
 
 
-def main():
-    f = load(sys.argv[1], "FETCH_SIZE")
-    w = load(sys.argv[2], "WRITE_SIZE")
+def traffic(fetch_csv, write_csv):
+    f = load(fetch_csv, "FETCH_SIZE")
+    w = load(write_csv, "WRITE_SIZE")
     res = {}
     for kname, rows in f.items():
         for pref, lib in NAMES.items():
@@ -50,6 +50,10 @@ def main():
                 fb = 2.0 * 1024.0 * sum(fetch) / len(fetch)
                 wb = 1024.0 * sum(write) / max(len(write), 1)
                 res[lib] = {"fetch_bytes": fb, "write_bytes": wb, "launches_sampled": len(fetch)}
+    return {"per_launch_bytes": {k: v["fetch_bytes"] + v["write_bytes"] for k, v in res.items()}, "detail": res}
+
+
+def stamp():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import subprocess
@@ -59,11 +63,14 @@ def main():
         dirty = bool(subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--", "kmerseek_amd/csrc"], text=True).strip())
     except Exception:
         commit, dirty = None, None
-    out = {"commit": commit, "kernel_sources_dirty_vs_commit": dirty, "kernel_sources_sha16": bench.kernel_sources_sha(),
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 0`",
-           "correction": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), WRITE_SIZE exact; KiB -> bytes",
-           "per_launch_bytes": {k: v["fetch_bytes"] + v["write_bytes"] for k, v in res.items()},
-           "detail": res}
+    return {"commit": commit, "kernel_sources_dirty_vs_commit": dirty, "kernel_sources_sha16": bench.kernel_sources_sha(),
+            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 0`",
+            "correction": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), WRITE_SIZE exact; KiB -> bytes"}
+
+
+def main():
+    out = stamp()
+    out.update(traffic(sys.argv[1], sys.argv[2]))
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out["per_launch_bytes"], indent=1))
