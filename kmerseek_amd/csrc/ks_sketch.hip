@@ -112,6 +112,7 @@ struct sk_args {
     u32 *part_cursor; // [256] records placed per region so far
     u64 part_cap;
     u32 part_K, part_mask; // region = ks_join_prefix(h, part_K) & part_mask
+    u32 part_kshift;       // != 0: part_K = 2^(32 - part_kshift), the prefix is a shift (sk_digit)
     u32 part_sub_shift;    // sub-regions per region = 1 << shift; a workgroup writes sub-region blockIdx.x & (that - 1)
 };
 
@@ -188,6 +189,13 @@ KS_DEV u32 sk_block_excl_scan1(u32 a, u32 *smem) {
 #pragma unroll
     for (u32 wv = 0; wv < SK_THREADS / 64; wv++) base += wv < wave ? smem[wv] : 0u;
     return base + ia - a;
+}
+
+// partition digit of a kept hash: the join prefix (ks_join_prefix) masked; at scaled = 1 the prefix multiplier is a power of
+// two and the quarter-rate multiply is a shift (kshift = 32 - log2 K; 0 = multiply)
+KS_DEV u32 sk_digit(u64 h, u32 K, u32 kshift, u32 mask) {
+    const u32 hi = (u32)(h >> 32);
+    return (kshift ? (hi >> kshift) : __umulhi(hi, K)) & mask;
 }
 
 #define SK_CTL_WORDS 32 // control block of a sketch call (see sketch_attempt)
@@ -381,8 +389,12 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     __shared__ u32 scan_smem[2 * (SK_THREADS / 64 + 1)];
     __shared__ u32 loff[SK_SEQ_CAP + 2];
     __shared__ u8 lut_s[256];
+#ifdef SK_LDS_PAD // diagnostic builds only: fewer workgroups per CU
+    __shared__ u32 lds_pad[SK_LDS_PAD / 4];
+    if (threadIdx.x == 0 && A.n_res == 0xfffffffffffffffULL) lds_pad[A.k] = 1;
+#endif
     __shared__ u32 bins[256];  // postings: count per digit, then the digit's start inside the tile
-    __shared__ u32 gbase[256]; // postings: the tile's slice of each digit's region
+    __shared__ unsigned long long gaddr[256]; // postings: slot of the tile's first element of each digit, minus the digit's start inside the tile
 
     const u32 tid = threadIdx.x;
     u8 *res_b = (u8 *)res_w;
@@ -501,6 +513,9 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     const u64 *wl = res_w + tid; // word at byte q0
     u64 h[SK_E];
     u32 bo[SK_E];
+    // (uniform) postings are wanted and this variant ranks them while it hashes (the compacting variant keeps the later pass)
+    const bool early = !CMP && A.part_keys != nullptr && B.in_lds;
+    u32 rkp[SK_E / 2] = {0, 0, 0, 0}; // ranks inside (tile, digit) of my windows, 16 bits each
     if (CMP) {
         // ---- phase 2, compacting variant: hash sub-tile by sub-tile, keep the windows under the threshold in an LDS list
         // (hash in tmp, its sequence in the counter words, which are not counting yet), then bucket the compacted list
@@ -589,6 +604,15 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         h[7] = sk_hash_window<7>(wl, A.k, A.seed);
 #pragma unroll
         for (int i = 0; i < SK_E; i++) bo[i] = sk_place_window(A, q0 + i, h[i], q, B, s_end, cnt);
+        // Postings (query side): a kept hash's rank inside its partition digit is one more LDS atomic — taken HERE, while the
+        // vector ALU is what the workgroup waits for and the LDS idles.  A tile without repeats (nearly all) then emits its
+        // postings straight from these window-order registers: no sequence lookup, no counting phase of its own.
+        if (early) {
+#pragma unroll
+            for (int i = 0; i < SK_E; i++)
+                if (bo[i] != 0xffffffffu)
+                    rkp[i >> 1] |= atomicAdd(&bins[sk_digit(h[i], A.part_K, A.part_kshift, A.part_mask)], 1u) << ((i & 1) * 16); // < SK_TILE
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < SK_E; i++) { h[i] = 0; bo[i] = 0xffffffffu; }
@@ -785,6 +809,29 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     u32 ab[SK_E / 2];     // abundance of my representatives, 16 bits each (<= SK_TILE)
 #pragma unroll
     for (int i = 0; i < SK_E / 2; i++) ab[i] = 0x00010001u;
+    u64 hs[SK_E]; // (fast posting path) my 8 sorted positions, to stage the CSR run again behind the postings
+    const bool fastp = early && !any_dup; // (uniform)
+    if (early && any_dup) { // the ranks taken while hashing counted the repeats too: count again below
+        if (tid < 256) bins[tid] = 0;
+        __syncthreads();
+    }
+    if (fastp) {
+#pragma unroll
+        for (int i = 0; i < SK_E; i++) {
+            const bool kept = bo[i] != 0xffffffffu;
+            rep |= (kept ? 1u : 0u) << i;
+            srl[i >> 2] |= (kept ? (bo[i] >> 24) : 0u) << (8 * (i & 3));
+            rk[i] = (rkp[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+        }
+        if (MODE == 0 && p0 < n_kept) { // (a medium tile writes its run out of tmp before its postings go through it)
+            const uint4 a = *(const uint4 *)&tmp[p0], b = *(const uint4 *)&tmp[p0 + 2], c = *(const uint4 *)&tmp[p0 + 4],
+                        d = *(const uint4 *)&tmp[p0 + 6];
+            hs[0] = (u64)a.x | ((u64)a.y << 32); hs[1] = (u64)a.z | ((u64)a.w << 32);
+            hs[2] = (u64)b.x | ((u64)b.y << 32); hs[3] = (u64)b.z | ((u64)b.w << 32);
+            hs[4] = (u64)c.x | ((u64)c.y << 32); hs[5] = (u64)c.z | ((u64)c.w << 32);
+            hs[6] = (u64)d.x | ((u64)d.y << 32); hs[7] = (u64)d.z | ((u64)d.w << 32);
+        }
+    } else
     if (any_dup || posts) { // (uniform)
     if ((tid & ~63u) * SK_E < n_kept) { // (whole waves: the sequence lookup below works with all lanes of a wave)
         {
@@ -879,7 +926,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     if (posts) {
 #pragma unroll
         for (int i = 0; i < SK_E; i++)
-            if (rep & (1u << i)) rk[i] = atomicAdd(&bins[ks_join_prefix(h[i], A.part_K) & A.part_mask], 1u);
+            if (rep & (1u << i)) rk[i] = atomicAdd(&bins[sk_digit(h[i], A.part_K, A.part_kshift, A.part_mask)], 1u);
     }
     __syncthreads(); // (tmp is read, the LDS buffers may be reused; the digit bins are counted)
     }
@@ -932,12 +979,18 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     auto post_offsets = [&]() {
         const u32 c = tid < 256 ? bins[tid] : 0;
         u32 off = 0;
-        if (c) {
-            off = atomicAdd(&A.part_cursor[(tid << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u))], c);
-            if ((u64)off + c > A.part_cap) atomicOr(&A.ticket[1], 2u); // region full: host falls back
-        }
+        const u32 seg = (tid << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u)); // (blockIdx.x & 7 names the XCD, i.e. the L2, these writes go through)
+        if (c) off = atomicAdd(&A.part_cursor[seg], c);
         const u32 ex = sk_block_excl_scan1(c, scan_smem);
-        if (tid < 256) { gbase[tid] = off; bins[tid] = ex; }
+        if (tid < 256) {
+            // element i of the digit-ordered tile goes to slot gaddr[digit] + i (the digit's start inside the tile taken off,
+            // modulo 2^64).  A digit whose slice does not fit its region (skewed hashes: the host is told and partitions
+            // this batch another way) lands in the SK_TILE spare slots behind the last region instead.
+            const bool fits = (u64)off + c <= A.part_cap;
+            if (c && !fits) atomicOr(&A.ticket[1], 2u);
+            gaddr[tid] = (fits ? (u64)seg * A.part_cap + off : A.part_cap * ((u64)(A.part_mask + 1u) << A.part_sub_shift)) - ex;
+            bins[tid] = ex;
+        }
     };
     // Postings, step 3 (after a barrier that follows post_offsets and the last reader of tmp / cnt): digit order through tmp,
     // sequence codes through the counter words, then one run per digit.
@@ -946,21 +999,20 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
 #pragma unroll
         for (int i = 0; i < SK_E; i++)
             if (rep & (1u << i)) {
-                const u32 pos = bins[ks_join_prefix(h[i], A.part_K) & A.part_mask] + rk[i];
+                const u32 pos = bins[sk_digit(h[i], A.part_K, A.part_kshift, A.part_mask)] + rk[i];
                 tmp[pos] = h[i];
                 qrel[pos] = (u16)((srl[i >> 2] >> (8 * (i & 3))) & 0xffu);
             }
         __syncthreads();
         for (u32 i = tid; i < n_distinct; i += SK_THREADS) {
             const u64 hh = tmp[i];
-            const u32 dg = ks_join_prefix(hh, A.part_K) & A.part_mask;
-            const u64 slot = (u64)gbase[dg] + (i - bins[dg]);
-            if (slot < A.part_cap) {
-                // (workgroups go round-robin to the XCDs, so blockIdx.x & 7 names the L2 these writes go through)
-                const u64 at = (u64)((dg << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u))) * A.part_cap + slot;
-                A.part_keys[at] = hh;
-                A.part_vals[at] = s_first + qrel[i];
-            }
+            const u64 at = gaddr[sk_digit(hh, A.part_K, A.part_kshift, A.part_mask)] + i;
+#ifndef SK_NO_POST_STORES // (diagnostic builds only: the kernel's time without the posting stores)
+            A.part_keys[at] = hh;
+            A.part_vals[at] = s_first + qrel[i];
+#else
+            if (at == 0xffffffffffffULL) A.part_vals[0] = (u32)hh + qrel[i];
+#endif
         }
     };
 
@@ -1000,6 +1052,10 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             __syncthreads();
             post_emit();
             __syncthreads();
+            if (fastp) {
+#pragma unroll
+                for (int i = 0; i < SK_E; i++) h[i] = hs[i];
+            }
         }
         if (B.in_lds) { // bucket starts are dead (dseq holds what the CSR needs)
             if (any_dup) stage_reps();
@@ -1798,12 +1854,14 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             u64 cap = per + per / 4 + 8192;                 // uniform hashes fill regions evenly; skew -> fallback
             cap = (cap + 8191) / 8192 * 8192;
             S->part_cap = cap;
-            SK_CHECK(ks_alloc(ctx, &S->part_keys, (size_t)(cap * n_segs)));
-            SK_CHECK(ks_alloc(ctx, &S->part_vals, (size_t)(cap * n_segs)));
+            // (+ SK_TILE spare slots behind the last region: where a tile drops a digit that does not fit its region)
+            SK_CHECK(ks_alloc(ctx, &S->part_keys, (size_t)(cap * n_segs) + SK_TILE));
+            SK_CHECK(ks_alloc(ctx, &S->part_vals, (size_t)(cap * n_segs) + SK_TILE));
             SK_CHECK(ks_alloc(ctx, &S->part_len, 2048));
             SK_HIPCHECK(hipMemsetAsync(S->part_len, 0, 2048 * sizeof(u32), ctx->stream));
             A.part_keys = S->part_keys; A.part_vals = S->part_vals; A.part_cursor = S->part_len; A.part_cap = cap;
             A.part_K = S->part_K; A.part_mask = S->part_regions - 1; A.part_sub_shift = S->part_sub_shift;
+            A.part_kshift = (S->part_K & (S->part_K - 1)) == 0 && S->part_K > 1 ? 32u - (u32)__builtin_ctz(S->part_K) : 0u;
         }
 
         // ---- medium / long sequences first: their unique counts feed the tile kernel's CSR prefix
