@@ -260,6 +260,14 @@ int ks_hits_pack64_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qid_base, u
  * all-ones in both value fields; the caller patches them from the gathered escape lists.  Asynchronous on ctx's stream. */
 int ks_hits_unpack64_device(ks_ctx *ctx, const uint64_t *d_packed, uint64_t n, int qbits, int tbits, uint32_t *d_qid,
                             uint32_t *d_tid, uint32_t *d_intersect, uint64_t *d_n_weighted);
+/* Index-sharded exchange, global (qid, tid) order: the gathered rows are n_blocks rank blocks (block r = block_rows[r] rows,
+ * host array), each ordered by (qid, tid), the ranks' target ranges ascending.  One counting merge (per (query, rank) run
+ * lengths by binary search -> exclusive scan -> one move) writes them ordered by (qid, tid) into the caller-owned output
+ * columns (device, sum(block_rows) entries; must not alias the inputs).  qid values must be < n_queries.  Asynchronous on
+ * ctx's stream.  (Rows per query as branchwater manysearch lists them: src/python/kmerseek/search.py:125-141.) */
+int ks_hits_merge_by_qid_device(ks_ctx *ctx, const uint32_t *d_qid, const uint32_t *d_tid, const uint32_t *d_intersect,
+                                const uint64_t *d_n_weighted, const uint64_t *block_rows, uint32_t n_blocks, uint32_t n_queries,
+                                uint32_t *d_out_qid, uint32_t *d_out_tid, uint32_t *d_out_intersect, uint64_t *d_out_n_weighted);
 void ks_hits_free(ks_hits *h);
 
 /* ---- measurement --------------------------------------------------------------------------- */

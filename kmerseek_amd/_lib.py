@@ -108,6 +108,7 @@ SIGNATURES = {
     "ks_hits_copy_to_device": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "ks_hits_pack64_to_device": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_uint32]),
     "ks_hits_unpack64_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "ks_hits_merge_by_qid_device": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "ks_hits_free": (None, [_vp]),
     "ks_timing_enable": (C.c_int, [_vp, C.c_int]),
     "ks_timing_reset": (C.c_int, [_vp]),

@@ -382,6 +382,89 @@ extern "C" int ks_hits_unpack64_device(ks_ctx *ctx, const uint64_t *d_packed, ui
     });
 }
 
+// ---------------------------------------------------------------------------------------------
+// Index-sharded exchange, global (qid, tid) order: the gathered list is W rank blocks, each ordered by (qid, tid) with the
+// ranks' target ranges ascending — so the merged order is "by qid, then by rank", and a row's place follows from counting,
+// not from sorting 10^7 keys: per (query, rank) the block's rows of that query are one run (found by binary search),
+// an exclusive scan over (qid-major, rank-minor) run lengths gives every run its start, one pass moves the rows.
+// Replaces a stable device sort on qid (torch.sort: ~8 passes over keys + 4 gathers).  Reference semantics: branchwater
+// manysearch rows per query (src/python/kmerseek/search.py:125-141).
+// ---------------------------------------------------------------------------------------------
+struct hm_blocks { u64 base[65]; u32 n; }; // rank r's rows are [base[r], base[r + 1])
+
+// first[r * (nq + 1) + q] = first row of block r whose qid is >= q (local to the block)
+__global__ __launch_bounds__(256) void k_hm_starts(const u32 *qid, hm_blocks B, u32 nq, u32 *first) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 per = (u64)nq + 1;
+    if (i >= per * B.n) return;
+    const u32 r = (u32)(i / per), q = (u32)(i % per);
+    u64 lo = B.base[r], hi = B.base[r + 1];
+    while (lo < hi) {
+        const u64 mid = lo + ((hi - lo) >> 1);
+        if (qid[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    first[i] = (u32)(lo - B.base[r]);
+}
+// run[q * W + r] = rows of query q in block r
+__global__ __launch_bounds__(256) void k_hm_runs(const u32 *first, u32 W, u32 nq, u32 *run) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (u64)nq * W) return;
+    const u32 q = (u32)(i / W), r = (u32)(i % W);
+    const u64 at = (u64)r * ((u64)nq + 1) + q;
+    run[i] = first[at + 1] - first[at];
+}
+__global__ __launch_bounds__(256) void k_hm_move(const u32 *qid, const u32 *tid, const u32 *isect, const u64 *nw, hm_blocks B, u32 nq,
+                                                 const u32 *first, const u32 *start, u32 *o_qid, u32 *o_tid, u32 *o_isect, u64 *o_nw) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B.base[B.n]) return;
+    u32 r = 0;
+    while (r + 1 < B.n && i >= B.base[r + 1]) r++; // (W <= 64 blocks)
+    const u32 q = qid[i];
+    if (q >= nq) return; // (an id beyond the declared range: dropped rather than written out of bounds; the caller checks counts)
+    const u64 pos = (u64)start[(u64)q * B.n + r] + ((i - B.base[r]) - first[(u64)r * ((u64)nq + 1) + q]);
+    o_qid[pos] = q; o_tid[pos] = tid[i]; o_isect[pos] = isect[i]; o_nw[pos] = nw[i];
+}
+
+extern "C" int ks_hits_merge_by_qid_device(ks_ctx *ctx, const uint32_t *d_qid, const uint32_t *d_tid, const uint32_t *d_intersect,
+                                           const uint64_t *d_n_weighted, const uint64_t *block_rows, uint32_t n_blocks, uint32_t n_queries,
+                                           uint32_t *d_out_qid, uint32_t *d_out_tid, uint32_t *d_out_intersect, uint64_t *d_out_n_weighted) {
+    return ks_guard(ctx, [&]() -> int {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (!block_rows || n_blocks == 0 || n_blocks > 64) return ks_fail(ctx, KS_ERR_INVALID_ARG, "merge: 1 .. 64 rank blocks");
+    hm_blocks B;
+    B.n = n_blocks; B.base[0] = 0;
+    for (u32 r = 0; r < n_blocks; r++) B.base[r + 1] = B.base[r] + block_rows[r];
+    const u64 n = B.base[n_blocks];
+    if (n == 0) return KS_OK;
+    if (n >= 0xffffffffULL) return ks_fail(ctx, KS_ERR_CAPACITY, "merge: %llu rows", (unsigned long long)n);
+    if (!d_qid || !d_tid || !d_intersect || !d_n_weighted || !d_out_qid || !d_out_tid || !d_out_intersect || !d_out_n_weighted)
+        return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    u32 *first = nullptr, *run = nullptr;
+    const u64 n_first = ((u64)n_queries + 1) * n_blocks, n_run = (u64)n_queries * n_blocks;
+    int st = ks_alloc(ctx, &first, (size_t)n_first);
+    if (st == KS_OK) st = ks_alloc(ctx, &run, (size_t)n_run + 1);
+    if (st == KS_OK) {
+        ks_timer_begin(ctx, "hits_merge");
+        hipLaunchKernelGGL(k_hm_starts, dim3((u32)((n_first + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)d_qid, B, n_queries, first);
+        if (n_run) hipLaunchKernelGGL(k_hm_runs, dim3((u32)((n_run + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)first, n_blocks, n_queries, run);
+        ks_timer_end(ctx);
+        if (n_run) st = ks_scan_u32_inplace(ctx, run, n_run, nullptr);
+    }
+    if (st == KS_OK) {
+        ks_timer_begin(ctx, "hits_merge");
+        hipLaunchKernelGGL(k_hm_move, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)d_qid, (const u32 *)d_tid,
+                           (const u32 *)d_intersect, (const u64 *)d_n_weighted, B, n_queries, (const u32 *)first, (const u32 *)run, d_out_qid,
+                           d_out_tid, d_out_intersect, (u64 *)d_out_n_weighted);
+        ks_timer_end(ctx);
+        if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "merge launch failed");
+    }
+    // (the scratch blocks go back to the pool in stream order: the next allocation on this context's stream comes behind the kernels)
+    ks_pool_free(ctx, first); ks_pool_free(ctx, run);
+    return st;
+    });
+}
+
 extern "C" void ks_hits_free(ks_hits *h) {
     if (!h) return;
     ks_pool_free(h->ctx, h->d_qid);

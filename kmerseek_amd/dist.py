@@ -146,8 +146,8 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
             if out is not None:
                 qid, tid, isect, nw = out
                 if sharded == "index" and order == "qid" and qid.numel():
-                    idx = torch.sort(qid, stable=True).indices
-                    qid, tid, isect, nw = qid[idx], tid[idx], isect[idx], nw[idx]
+                    qid, tid, isect, nw = _order_by_qid(hits, on_device, (qid, tid, isect, nw), counts, id_counts[0], dev,
+                                                        own_stream_sync, torch_stream_sync)
                 return qid, tid, isect, nw
             # (more rows with wide values than the escape list takes: the columns travel unpacked below)
 
@@ -179,9 +179,29 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
     cols = list(zip(*[columns(recv[r * 5 * cap:(r + 1) * 5 * cap], c) for r, c in enumerate(counts)]))
     qid, tid, isect, nw = (torch.cat(c) for c in cols)  # one pass: the blocks are padded to the largest shard
     if sharded == "index" and order == "qid" and qid.numel():
-        idx = torch.sort(qid, stable=True).indices  # inside one qid, rank order already is tid order
-        qid, tid, isect, nw = qid[idx], tid[idx], isect[idx], nw[idx]
+        qid, tid, isect, nw = _order_by_qid(hits, on_device, (qid, tid, isect, nw), counts, id_counts[0] if id_counts else None, dev,
+                                            own_stream_sync, torch_stream_sync)
     return qid, tid, isect, nw
+
+
+def _order_by_qid(hits, on_device, cols, counts, n_queries, dev, own_stream_sync, torch_stream_sync):
+    """Rank blocks (each ordered by (qid, tid), target ranges ascending with the rank) -> one list ordered by (qid, tid).
+    On the device with the library at hand: a counting merge (ks_hits_merge_by_qid_device — run lengths per (query, rank) by
+    binary search, one scan, one move); otherwise a stable sort on qid (inside one qid, rank order already is tid order)."""
+    import torch
+    qid, tid, isect, nw = cols
+    if on_device and dev.type == "cuda":
+        if n_queries is None:
+            n_queries = int(qid.max()) + 1
+        out = (torch.empty_like(qid), torch.empty_like(tid), torch.empty_like(isect), torch.empty_like(nw))
+        qid, tid, isect, nw = (c.contiguous() for c in cols)
+        torch_stream_sync()  # the columns were produced on torch's stream; the merge runs on the context's
+        hits._ctx.merge_hits_by_qid_device(qid.data_ptr(), tid.data_ptr(), isect.data_ptr(), nw.data_ptr(), counts, n_queries,
+                                           *(o.data_ptr() for o in out))
+        own_stream_sync()
+        return out
+    idx = torch.sort(qid, stable=True).indices
+    return qid[idx], tid[idx], isect[idx], nw[idx]
 
 
 class _DeviceColumn:

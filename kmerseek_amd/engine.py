@@ -179,6 +179,15 @@ class Context:
         self._check(self._L.ks_hits_unpack64_device(self._h, C.c_void_p(d_packed), n, qbits, tbits, C.c_void_p(d_qid), C.c_void_p(d_tid),
                                                     C.c_void_p(d_isect), C.c_void_p(d_nw)))
 
+    def merge_hits_by_qid_device(self, d_qid: int, d_tid: int, d_isect: int, d_nw: int, block_rows: Sequence[int], n_queries: int,
+                                 o_qid: int, o_tid: int, o_isect: int, o_nw: int):
+        """Rank blocks of a gathered index-sharded hit list -> one list ordered by (qid, tid), all device pointers
+        (ks_hits_merge_by_qid_device: a counting merge instead of a sort)."""
+        rows = (C.c_uint64 * len(block_rows))(*[int(x) for x in block_rows])
+        self._check(self._L.ks_hits_merge_by_qid_device(self._h, C.c_void_p(d_qid), C.c_void_p(d_tid), C.c_void_p(d_isect), C.c_void_p(d_nw),
+                                                        rows, len(block_rows), int(n_queries), C.c_void_p(o_qid), C.c_void_p(o_tid),
+                                                        C.c_void_p(o_isect), C.c_void_p(o_nw)))
+
     def reload_debug_env(self):
         """Re-read the KS_DEBUG_* variables (diagnostics: the library reads them only when a context is created)."""
         self._check(self._L.ks_ctx_reload_debug_env(self._h))

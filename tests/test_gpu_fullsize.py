@@ -168,10 +168,15 @@ def test_baseline_configs4_200k_all_vs_all_hp_k24_full_size(ctx):
             parts.append(ksd.all_gather_hits_device(h, tid_base=s0, device=dev, sharded="index"))
             h.free(); ix.free(); Ti.free()
         cat = [torch.cat([part[c] for part in parts]) for c in range(4)]
-        order = torch.sort(cat[0], stable=True).indices  # what the N-rank gather does after concatenating rank blocks
-        got = [c[order].cpu().numpy() for c in cat]
+        # what the N-rank gather does with the concatenated rank blocks for order="qid": the library's counting merge
+        # (ks_hits_merge_by_qid_device) — each block is (qid, tid)-ordered, the target ranges ascend with the rank
+        merged = ksd._order_by_qid(H, True, tuple(cat), [int(part[0].numel()) for part in parts], len(p[1]) - 1, dev,
+                                   ctx.synchronize, lambda: torch.cuda.current_stream(dev).synchronize())
+        got = [c.cpu().numpy() for c in merged]
         assert np.array_equal(got[0].view(np.uint32), qid) and np.array_equal(got[1].view(np.uint32), tid)
         assert np.array_equal(got[2].view(np.uint32), isect) and np.array_equal(got[3].view(np.uint64), nw)
+        order = torch.sort(cat[0], stable=True).indices  # ... and the stable sort it replaces agrees
+        assert all(torch.equal(c[order], m) for c, m in zip(cat, merged))
         H.free(); Q.free(); index.free(); S.free()
     finally:
         dr.free(); do.free()
