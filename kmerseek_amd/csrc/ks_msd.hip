@@ -119,13 +119,21 @@ __global__ __launch_bounds__(MS_THREADS, 2) void k_msd_scatter(const u64 *kin, u
     }
     __syncthreads();
     {
-        // (NB <= MS_THREADS: thread b owns bin b)
-        const u32 c = tid < NB ? cnt[tid] : 0u;
+        // thread t owns bins t * BPT .. t * BPT + BPT - 1 (BPT = 1 up to NB = 512 bins, 2 for the 1024-bin window)
+        constexpr u32 BPT = (NB + MS_THREADS - 1) / MS_THREADS;
+        u32 c[BPT], sum = 0;
+#pragma unroll
+        for (u32 j = 0; j < BPT; j++) { const u32 b = tid * BPT + j; c[j] = b < NB ? cnt[b] : 0u; sum += c[j]; }
         u32 total;
-        const u32 ds = ks_block_excl_scan(c, scan_smem, &total);
-        if (tid < NB) {
-            dstart[tid] = ds;
-            gbase[tid] = c ? atomicAdd(&cur[base + tid], c) : 0u;
+        u32 ds = ks_block_excl_scan(sum, scan_smem, &total);
+#pragma unroll
+        for (u32 j = 0; j < BPT; j++) {
+            const u32 b = tid * BPT + j;
+            if (b < NB) {
+                dstart[b] = ds;
+                gbase[b] = c[j] ? atomicAdd(&cur[base + b], c[j]) : 0u;
+                ds += c[j];
+            }
         }
     }
     __syncthreads();
@@ -395,10 +403,14 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
     if (nbits <= 16 || n < 65536 || n >= 0xffffffffULL || ks_dbg(ctx, KS_DBG_PAIRS_LSD)) return KS_OK;
     // level 2 is as wide as it takes for ~768 records per bucket (0 .. 8 bits): a short list does not pay 65,536 buckets
     // ... and then as wide as it takes to save a local pass (remaining bits a multiple of 8): passes cost more than buckets
+    // (up to 9 bits: 131,072 buckets through a 1024-bin window — lists beyond ~40 M records, where 65,536 buckets would leave
+    // an average of ~750 and the heavy rows of an all-vs-all push half of them past what one wave sorts: 0.75 of 3.6 ms
+    // went to k_msd_local_big at 200k x 200k hp)
     int bits2 = 0;
-    while (bits2 < 8 && (n >> (8 + bits2)) > 768) bits2++;
+    while (bits2 < 9 && (n >> (8 + bits2)) > (bits2 < 8 ? 768u : 560u)) bits2++;
     for (int b = bits2 + 1; b <= 8 && nbits - 8 - b > 0; b++)
         if ((nbits - 8 - b + 7) / 8 < (nbits - 8 - bits2 + 7) / 8) { bits2 = b; break; }
+    if (nbits - 8 - bits2 <= 0) bits2 = nbits - 9 > 0 ? nbits - 9 : 0; // (at least one bit left for the local sort)
     const int shift1 = lo_bit + nbits - 8, shift2 = shift1 - bits2;
     const u32 mask2 = (1u << (8 + bits2)) - 1u, n_buckets = 1u << (8 + bits2);
     const u32 n_tiles = (u32)((n + MS_TILE - 1) / MS_TILE);
@@ -415,7 +427,7 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
     // (level 1 followed by level 2: MS_SUB histograms; level 1 alone — short lists — one, whose spent cursors are the ends)
     const u32 n_sub = bits2 > 0 ? MS_SUB : 1u, sub_stride = bits2 > 0 ? 256u : 0u;
     const size_t off2_words = bits2 > 0 ? (size_t)n_buckets + 1 : 0, n_zero = 256 * MS_SUB + off2_words + 1;
-    int st = ks_alloc(ctx, &blk, n_zero + 65536 + 1);
+    int st = ks_alloc(ctx, &blk, n_zero + (size_t)(n_buckets > 65536u ? n_buckets : 65536u) + 1);
     u32 *off1 = blk, *off2 = blk ? blk + 256 * MS_SUB : nullptr, *big = blk ? blk + 256 * MS_SUB + off2_words : nullptr;
     u64 *sorted_in = ka; // where the partitioned list ends up
     if (st == KS_OK) {
@@ -435,12 +447,14 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
     const u32 *off = off1;
     if (st == KS_OK && bits2 > 0) {
         ks_timer_begin(ctx, "msd_hist");
-        hipLaunchKernelGGL((k_msd_hist<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, n, shift2, off2, mask2, bits2, 0u);
+        if (bits2 <= 8) hipLaunchKernelGGL((k_msd_hist<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, n, shift2, off2, mask2, bits2, 0u);
+        else hipLaunchKernelGGL((k_msd_hist<1024>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, n, shift2, off2, mask2, bits2, 0u);
         ks_timer_end(ctx);
         st = ks_scan_u32_inplace(ctx, off2, n_buckets, nullptr);
         if (st == KS_OK) {
             ks_timer_begin(ctx, "msd_scatter");
-            hipLaunchKernelGGL((k_msd_scatter<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, ka, n, shift2, off2, mask2, bits2, 0u);
+            if (bits2 <= 8) hipLaunchKernelGGL((k_msd_scatter<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, ka, n, shift2, off2, mask2, bits2, 0u);
+            else hipLaunchKernelGGL((k_msd_scatter<1024>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, ka, n, shift2, off2, mask2, bits2, 0u);
             ks_timer_end(ctx);
             sorted_in = ka;
             off = off2;
