@@ -103,13 +103,16 @@ class Env:
             self.dist.barrier()
         self.torch.cuda.synchronize(self.dev)
 
-    def timed(self, fn, steps):
-        """EXACTLY `steps` calls of fn between barrier + synchronize on both sides; max over ranks."""
+    def timed(self, fn, steps, finalize=None):
+        """EXACTLY `steps` calls of fn between barrier + synchronize on both sides; max over ranks.  `finalize(out)` runs
+        inside the timed region after the last call (a pipelined step completes its last exchange there)."""
         self.barrier()
         t0 = time.perf_counter()
         out = None
         for _ in range(steps):
             out = fn()
+        if finalize is not None:
+            out = finalize(out)
         self.barrier()
         el = time.perf_counter() - t0
         if self.world > 1:
@@ -539,27 +542,40 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
     torch.cuda.synchronize(env.dev)
     index_build_s = time.time() - t0
 
+    pending = [None]
+
     def step():
         Q = ctx.sketch_queries_device(index, p_res.data_ptr(), p_off.data_ptr(), n_prot, n_res, max_seq_len=q_maxlen)
         H = ctx.search(index, Q)
         # per-shard hit lists all-gathered on the device; left in rank-major order (each shard's block is (qid, tid)-ordered),
-        # as configs[4] states it — a global (qid, tid) order is one more stable device sort (order="qid") a consumer may ask for
-        # The rows travel as 64-bit transport words (8 instead of 20 bytes per row over xGMI; rows with wide values on an escape list).
-        rows = ksd.all_gather_hits_device(H, tid_base=s0, device=env.cdev, sharded="index", order="shard", id_counts=(n_prot, n_prot))
-        out = (Q.n_hashes, H.count, H.n_pair_instances, int(rows[0].numel()))
+        # as configs[4] states it — a global (qid, tid) order is one counting merge more (order="qid") a consumer may ask for.
+        # The rows travel as 64-bit transport words (8 instead of 20 bytes per row over xGMI; rows with wide values on an escape
+        # list), and the exchange is PIPELINED: this step's collective is started here and completed while the next step's
+        # kernels run (over xGMI the exchange, not the kernels, is the step of this config at 8 GPUs).
+        nxt = ksd.begin_all_gather_hits_device(H, tid_base=s0, device=env.cdev, sharded="index", order="shard", id_counts=(n_prot, n_prot))
+        rows = pending[0].finish() if pending[0] is not None else None
+        pending[0] = nxt
+        out = (Q.n_hashes, H.count, H.n_pair_instances)
         H.free()
         Q.free()
         return out, rows
 
+    def drain(out):
+        rows = pending[0].finish()
+        pending[0] = None
+        return out[0], rows
+
     for _ in range(max(args.warmup, 1)):
         stats, rows = step()
-    elapsed, (stats, rows) = env.timed(step, args.steps)
+    stats, rows = drain((stats, rows))
+    elapsed, (stats, rows) = env.timed(step, args.steps, finalize=drain)
     # per-kernel table + roofline of this config (untimed pass with every launch bracketed by HIP events on the launch stream)
     n_t_postings = index.n_postings
     ctx.timing_reset()
     ctx.timing_enable(1)
     for _ in range(2):
         step()
+    drain((None, None))
     ctx.timing_enable(False)
     timing_all = {k_: (n_ / 2, ms_ / 2) for k_, (n_, ms_) in ctx.timing().items()}
     # the gathered list is complete and holds every (qid, tid) pair once: checked once, outside the timed region, by sorting

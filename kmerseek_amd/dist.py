@@ -234,9 +234,33 @@ def _hit_columns_as_torch(hits, n: int, dev):
         return None
 
 
+class PendingGather:
+    """An exchange whose collective has been started (``begin_all_gather_hits_device``): ``finish()`` waits for it and returns
+    the gathered columns.  Between the two the caller may launch the next step's kernels — over xGMI the exchange, not the
+    kernels, is the step of an index-sharded all-vs-all, and the collective (RCCL runs it on a stream of its own) moves the
+    previous step's rows while the next step is sketched and joined."""
+
+    def __init__(self, finish=None, result=None):
+        self._finish, self._result = finish, result
+
+    def finish(self):
+        if self._finish is not None:
+            self._result = self._finish()
+            self._finish = None
+        return self._result
+
+
 def _gather_packed(hits, on_device, n_local, counts, qid_base, tid_base, qbits, tbits, dev, own_stream_sync, torch_stream_sync):
-    """The exchange with 64-bit transport words.  Block of a rank (i64 words): packed[cap] | n_esc | esc_row (u32 x esc_cap)
-    | esc_intersect (u32 x esc_cap) | esc_n_weighted (u64 x esc_cap).  None if some rank had more escapes than esc_cap."""
+    """The exchange with 64-bit transport words, start to end.  None if some rank had more escapes than the lists take."""
+    return _gather_packed_begin(hits, on_device, n_local, counts, qid_base, tid_base, qbits, tbits, dev, own_stream_sync,
+                                torch_stream_sync, async_op=False)()
+
+
+def _gather_packed_begin(hits, on_device, n_local, counts, qid_base, tid_base, qbits, tbits, dev, own_stream_sync, torch_stream_sync,
+                         async_op):
+    """Packs this rank's rows and STARTS the collective; returns the function that completes the exchange.
+    Block of a rank (i64 words): packed[cap] | n_esc | esc_row (u32 x esc_cap) | esc_intersect (u32 x esc_cap) |
+    esc_n_weighted (u64 x esc_cap).  The completion returns None if some rank had more escapes than esc_cap."""
     import torch
     dist = _dist()
     world = len(counts)
@@ -268,40 +292,97 @@ def _gather_packed(hits, on_device, n_local, counts, qid_base, tid_base, qbits, 
             send[cap + 1 + esc_cap // 2:cap + 1 + esc_cap] = torch.from_numpy(ei.view(np.int64)).to(dev)
             send[cap + 1 + esc_cap:] = torch.from_numpy(en.view(np.int64)).to(dev)
     recv = torch.empty(world * words, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(recv, send)
-    blocks = [recv[r * words:(r + 1) * words] for r in range(world)]
-    n_esc = [int(x) for x in torch.stack([b[cap] for b in blocks]).tolist()]
-    if max(n_esc) > esc_cap:
-        return None
-    total = sum(counts)
-    if on_device and total:
-        # one native pass per shard straight into the gathered columns (instead of a concatenation and a dozen elementwise
-        # kernels over the whole list)
-        ctx = hits._ctx
-        qid = torch.empty(total, dtype=torch.int32, device=dev); tid = torch.empty(total, dtype=torch.int32, device=dev)
-        isect = torch.empty(total, dtype=torch.int32, device=dev); nw = torch.empty(total, dtype=torch.int64, device=dev)
-        torch_stream_sync()  # (the collective that filled `recv` ran on torch's stream)
-        at = 0
-        for b, c in zip(blocks, counts):
-            if c:
-                ctx.unpack_hits64_device(b.data_ptr(), c, qbits, tbits, qid.data_ptr() + 4 * at, tid.data_ptr() + 4 * at,
-                                         isect.data_ptr() + 4 * at, nw.data_ptr() + 8 * at)
-            at += c
-        own_stream_sync()
-    else:
-        w = torch.cat([b[:c] for b, c in zip(blocks, counts)])
-        qid = ((w >> (tbits + 2 * v)) & ((1 << qbits) - 1)).to(torch.int32)
-        tid = ((w >> (2 * v)) & ((1 << tbits) - 1)).to(torch.int32)
-        isect = ((w >> v) & vmax).to(torch.int32)
-        nw = w & vmax
-    off = 0
-    for b, c, ne in zip(blocks, counts, n_esc):
-        if ne:
-            rows = b[cap + 1:cap + 1 + esc_cap // 2].view(torch.int32)[:ne].to(torch.int64) + off
-            isect[rows] = b[cap + 1 + esc_cap // 2:cap + 1 + esc_cap].view(torch.int32)[:ne]
-            nw[rows] = b[cap + 1 + esc_cap:cap + 1 + 2 * esc_cap][:ne]
-        off += c
-    return qid, tid, isect, nw
+    work = dist.all_gather_into_tensor(recv, send, async_op=True) if async_op else dist.all_gather_into_tensor(recv, send)
+    ctx = hits._ctx if on_device else None
+
+    def finish():
+        if work is not None and hasattr(work, "wait"):
+            work.wait()  # (RCCL: the current stream waits for the collective; gloo: the host does)
+        keep = send  # noqa: F841  (the send block lives until the collective is done)
+        blocks = [recv[r * words:(r + 1) * words] for r in range(world)]
+        n_esc = [int(x) & 0xffffffff for x in torch.stack([b[cap] for b in blocks]).tolist()]
+        if max(n_esc) > esc_cap:
+            return None
+        total = sum(counts)
+        if on_device and total:
+            # one native pass per shard straight into the gathered columns (instead of a concatenation and a dozen
+            # elementwise kernels over the whole list)
+            qid = torch.empty(total, dtype=torch.int32, device=dev); tid = torch.empty(total, dtype=torch.int32, device=dev)
+            isect = torch.empty(total, dtype=torch.int32, device=dev); nw = torch.empty(total, dtype=torch.int64, device=dev)
+            torch_stream_sync()  # (the collective that filled `recv` ran on torch's side)
+            at = 0
+            for b, c in zip(blocks, counts):
+                if c:
+                    ctx.unpack_hits64_device(b.data_ptr(), c, qbits, tbits, qid.data_ptr() + 4 * at, tid.data_ptr() + 4 * at,
+                                             isect.data_ptr() + 4 * at, nw.data_ptr() + 8 * at)
+                at += c
+            own_stream_sync()
+        else:
+            w = torch.cat([b[:c] for b, c in zip(blocks, counts)])
+            qid = ((w >> (tbits + 2 * v)) & ((1 << qbits) - 1)).to(torch.int32)
+            tid = ((w >> (2 * v)) & ((1 << tbits) - 1)).to(torch.int32)
+            isect = ((w >> v) & vmax).to(torch.int32)
+            nw = w & vmax
+        off = 0
+        for b, c, ne in zip(blocks, counts, n_esc):
+            if ne:
+                rows = b[cap + 1:cap + 1 + esc_cap // 2].view(torch.int32)[:ne].to(torch.int64) + off
+                isect[rows] = b[cap + 1 + esc_cap // 2:cap + 1 + esc_cap].view(torch.int32)[:ne]
+                nw[rows] = b[cap + 1 + esc_cap:cap + 1 + 2 * esc_cap][:ne]
+            off += c
+        return qid, tid, isect, nw
+    return finish
+
+
+def begin_all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=None, sharded: str = "queries",
+                                 order: str = "qid", id_counts: Optional[Tuple[int, int]] = None) -> PendingGather:
+    """``all_gather_hits_device`` in two halves: the rows are packed and the collective is STARTED here; ``finish()`` of the
+    returned object delivers the gathered columns.  Only the transport-word exchange of device-resident hits on more than one
+    rank really runs in the background (the count exchange before it is a few bytes); everything else completes here.
+    The hit list may be freed as soon as this returns (its rows are in the send block)."""
+    import torch
+    rank, world = world_info()
+    dev = device if device is not None else torch.device("cpu")
+    on_device = hasattr(hits, "copy_to_device") and dev.type == "cuda"
+    if world == 1 or not on_device or id_counts is None or _bits_for(id_counts[0]) + _bits_for(id_counts[1]) > 48:
+        return PendingGather(result=all_gather_hits_device(hits, qid_base, tid_base, device, sharded, order, id_counts))
+    dist = _dist()
+    n_local = int(hits.count)
+    mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    allc = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allc, mine)
+    counts = [int(c) for c in allc.tolist()]
+    ctx = hits._ctx
+
+    def own_stream_sync():
+        if ctx.stream != torch.cuda.current_stream(dev).cuda_stream:
+            ctx.synchronize()
+
+    def torch_stream_sync():
+        if ctx.stream != torch.cuda.current_stream(dev).cuda_stream:
+            torch.cuda.current_stream(dev).synchronize()
+
+    qbits, tbits = _bits_for(id_counts[0]), _bits_for(id_counts[1])
+    if n_local and (qid_base >= max(id_counts[0], 1) or tid_base >= max(id_counts[1], 1)):
+        raise ValueError(f"id bases ({qid_base}, {tid_base}) do not fit id_counts {tuple(id_counts)}")
+    # (a private handle: the caller frees `hits` right away, the completion still needs its context)
+    fin = _gather_packed_begin(hits, True, n_local, counts, qid_base, tid_base, qbits, tbits, dev, own_stream_sync, torch_stream_sync,
+                               async_op=True)
+
+    class _CtxOnly:  # what _order_by_qid needs of a hit list
+        _ctx = ctx
+
+    def finish():
+        out = fin()
+        if out is None:
+            raise RuntimeError("more rows with wide values than the escape lists take: repeat this exchange with "
+                               "all_gather_hits_device (unpacked columns)")
+        qid, tid, isect, nw = out
+        if sharded == "index" and order == "qid" and qid.numel():
+            qid, tid, isect, nw = _order_by_qid(_CtxOnly, True, (qid, tid, isect, nw), counts, id_counts[0], dev, own_stream_sync,
+                                                torch_stream_sync)
+        return qid, tid, isect, nw
+    return PendingGather(finish=finish)
 
 
 def all_gather_hits(hits, qid_base: int = 0, tid_base: int = 0, device=None, sharded: str = "queries",
