@@ -134,9 +134,13 @@ KS_DEV u32 sk_lower_bound(const u64 *a, u32 lo, u32 hi, u64 x) { // first i in [
     return lo;
 }
 
-// hash of the window that starts at LDS byte `pos8 + I` where pos8 is 8-byte aligned
-template <int I>
-KS_DEV u64 sk_hash_window(const u64 *w /* LDS words starting at pos8 */, u32 k, u64 seed) {
+// hash of the window that starts at LDS byte `pos8 + I` where pos8 is 8-byte aligned.  KC != 0: k is the compile-time
+// constant KC (the launches of the common k-mer sizes): the block loop, the tail branches and the byte masks fold away and a
+// tail of <= 4 bytes multiplies as a 32-bit value — ~56 instead of ~90 vector instructions per window at k = 10, where
+// the hash phase is what the vector ALU is busy with (profiles/).
+template <int I, int KC = 0>
+KS_DEV u64 sk_hash_window(const u64 *w /* LDS words starting at pos8 */, u32 k_rt, u64 seed) {
+    const u32 k = KC ? (u32)KC : k_rt;
     ks_murmur m;
     m.init(seed);
     const u32 nb = k >> 4, t = k & 15;
@@ -331,16 +335,16 @@ __global__ __launch_bounds__(256) void k_tile_plan(const u64 *offs, u32 n_seqs, 
 // Compacting variant, windows [p0 + H, p0 + H + 4) of a thread: hash, keep what passes the threshold, append to the LDS list
 // (hash -> hlist, sequence relative to the tile's first -> slist): wave scan of the per-lane keep counts, one LDS atomic
 // per wave.  Entries beyond SK_TILE are dropped (the cursor keeps counting: the tile then reports the overflow).
-template <int H>
+template <int H, int KC>
 KS_DEV void sk_cmp_half(const sk_args &A, const sk_bounds &B, sk_seq &q, const u64 *wl, u32 p0, bool active, u32 s_first, u32 s_end,
                         u32 lane, u64 *hlist, u8 *slist, u32 *cursor) {
     u64 h[4];
     u32 keep = 0, sr = 0; // keep mask of the 4 windows, their sequences (one byte each)
     if (active) {
-        h[0] = sk_hash_window<H + 0>(wl, A.k, A.seed);
-        h[1] = sk_hash_window<H + 1>(wl, A.k, A.seed);
-        h[2] = sk_hash_window<H + 2>(wl, A.k, A.seed);
-        h[3] = sk_hash_window<H + 3>(wl, A.k, A.seed);
+        h[0] = sk_hash_window<H + 0, KC>(wl, A.k, A.seed);
+        h[1] = sk_hash_window<H + 1, KC>(wl, A.k, A.seed);
+        h[2] = sk_hash_window<H + 2, KC>(wl, A.k, A.seed);
+        h[3] = sk_hash_window<H + 3, KC>(wl, A.k, A.seed);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const u32 p = p0 + H + i;
@@ -377,7 +381,7 @@ KS_DEV void sk_cmp_half(const sk_args &A, const sk_bounds &B, sk_seq &q, const u
 // the windows that pass the threshold are appended to an LDS list (wave scan of the per-lane keep counts + one LDS
 // atomic per wave), and the sort / unique phases run ONCE over the compacted list: the same number of kept hashes per
 // tile as at scaled = 1.  Bucket space shrinks with it: sequence s gets buckets [ls / c + srel, ... + ceil(nw / c)).
-template <int MODE, int CMP>
+template <int MODE, int CMP, int KC>
 KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     static_assert(!(CMP && MODE), "the compacting variant is for shared tiles");
     __shared__ __attribute__((aligned(16))) u64 res_w[(SK_TILE + SK_PAD) / 8];
@@ -543,8 +547,8 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                 sk_load_seq(q, A, B, s_end);
             }
             // two halves of 4 windows: 8 live hashes next to the prefetched residues do not fit the register budget
-            sk_cmp_half<0>(A, B, q, wl, p0, active, s_first, s_end, lane, tmp, slist, &n_list_s);
-            sk_cmp_half<4>(A, B, q, wl, p0, active, s_first, s_end, lane, tmp, slist, &n_list_s);
+            sk_cmp_half<0, KC>(A, B, q, wl, p0, active, s_first, s_end, lane, tmp, slist, &n_list_s);
+            sk_cmp_half<4, KC>(A, B, q, wl, p0, active, s_first, s_end, lane, tmp, slist, &n_list_s);
             __syncthreads(); // the sub-tile is hashed (its residues may be overwritten) and its appends are visible
         }
         const u32 n_list = n_list_s;
@@ -594,14 +598,14 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     // a tile's sequences end, on average, two thirds of the way through its SK_TILE positions: the threads behind
     // the last residue (whole waves, mostly) have nothing to hash
     if (q0 < B.at(s_end)) {
-        h[0] = sk_hash_window<0>(wl, A.k, A.seed);
-        h[1] = sk_hash_window<1>(wl, A.k, A.seed);
-        h[2] = sk_hash_window<2>(wl, A.k, A.seed);
-        h[3] = sk_hash_window<3>(wl, A.k, A.seed);
-        h[4] = sk_hash_window<4>(wl, A.k, A.seed);
-        h[5] = sk_hash_window<5>(wl, A.k, A.seed);
-        h[6] = sk_hash_window<6>(wl, A.k, A.seed);
-        h[7] = sk_hash_window<7>(wl, A.k, A.seed);
+        h[0] = sk_hash_window<0, KC>(wl, A.k, A.seed);
+        h[1] = sk_hash_window<1, KC>(wl, A.k, A.seed);
+        h[2] = sk_hash_window<2, KC>(wl, A.k, A.seed);
+        h[3] = sk_hash_window<3, KC>(wl, A.k, A.seed);
+        h[4] = sk_hash_window<4, KC>(wl, A.k, A.seed);
+        h[5] = sk_hash_window<5, KC>(wl, A.k, A.seed);
+        h[6] = sk_hash_window<6, KC>(wl, A.k, A.seed);
+        h[7] = sk_hash_window<7, KC>(wl, A.k, A.seed);
 #pragma unroll
         for (int i = 0; i < SK_E; i++) bo[i] = sk_place_window(A, q0 + i, h[i], q, B, s_end, cnt);
         // Postings (query side): a kept hash's rank inside its partition digit is one more LDS atomic — taken HERE, while the
@@ -1147,18 +1151,18 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
 
 // MODE 0: one shared tile per workgroup, ids in dispatch order (the look-back relies on it).  MODE 1: the medium
 // sequences — their number is only known on the device (*A.n_list), so a fixed grid strides over the list.
-template <int MODE, int CMP>
+template <int MODE, int CMP, int KC>
 // (medium tiles — a side launch of few workgroups — may take more registers instead of spilling: 2 workgroups per CU)
 __global__ __launch_bounds__(SK_THREADS, MODE == 1 ? 4 : SK_MINW) void k_sketch_tiles(sk_args A) {
     if (MODE == 1) {
         const u32 n = *A.n_list < A.n_list_cap ? *A.n_list : A.n_list_cap;
         for (u32 t = blockIdx.x; t < n; t += gridDim.x) {
-            sk_tile_body<MODE, CMP>(A, t);
+            sk_tile_body<MODE, CMP, KC>(A, t);
             __syncthreads(); // the next sequence re-initialises the LDS state
         }
     } else {
         if (A.n_tiles_dev && blockIdx.x >= *A.n_tiles_dev) return; // (uniform)
-        sk_tile_body<MODE, CMP>(A, blockIdx.x);
+        sk_tile_body<MODE, CMP, KC>(A, blockIdx.x);
     }
 }
 
@@ -1882,7 +1886,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             M.out_cap = ~0ULL;
             M.n_list = n_cls; M.n_list_cap = (u32)n_med;
             ks_timer_begin(ctx, "sketch_medium");
-            hipLaunchKernelGGL((k_sketch_tiles<1, 0>), dim3((u32)(n_med < 2048 ? n_med : 2048)), dim3(SK_THREADS), 0, ctx->stream, M);
+            hipLaunchKernelGGL((k_sketch_tiles<1, 0, 0>), dim3((u32)(n_med < 2048 ? n_med : 2048)), dim3(SK_THREADS), 0, ctx->stream, M);
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
         }
@@ -1950,8 +1954,19 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                 else if (A.part_cursor) SK_HIPCHECK(hipMemsetAsync(A.part_cursor, 0, 2048 * sizeof(u32), ctx->stream));
             }
             ks_timer_begin(ctx, "sketch_tiles");
-            if (compact) hipLaunchKernelGGL((k_sketch_tiles<0, 1>), dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
-            else hipLaunchKernelGGL((k_sketch_tiles<0, 0>), dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A);
+            // (the k-mer sizes of the reference's defaults and of BASELINE's configs run kernels with k folded in:
+            // src/rust/main.rs:28 k = 10, src/python/kmerseek/index.py:79-81 k = 24; any other size: the generic kernel)
+#define SK_LAUNCH_TILES(CMP_, KC_) hipLaunchKernelGGL((k_sketch_tiles<0, CMP_, KC_>), dim3((u32)n_tiles), dim3(SK_THREADS), 0, ctx->stream, A)
+            if (compact) {
+                if (p->ksize == 16) SK_LAUNCH_TILES(1, 16);
+                else if (p->ksize == 24) SK_LAUNCH_TILES(1, 24);
+                else SK_LAUNCH_TILES(1, 0);
+            } else {
+                if (p->ksize == 10) SK_LAUNCH_TILES(0, 10);
+                else if (p->ksize == 7) SK_LAUNCH_TILES(0, 7);
+                else SK_LAUNCH_TILES(0, 0);
+            }
+#undef SK_LAUNCH_TILES
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
 
