@@ -35,7 +35,7 @@ def main():
             continue
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f[0])):
-            if r["Kernel_Name"].startswith("void k_sketch_tiles<0, 0>"):
+            if r["Kernel_Name"].startswith("void k_sketch_tiles<0, 0"):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         w = sum(acc["SQ_WAVES"]) / len(acc["SQ_WAVES"])
         d = {k: sum(v) / len(v) / w for k, v in acc.items() if k != "SQ_WAVES"}

@@ -14,15 +14,17 @@ import os
 import sys
 
 NAMES = {  # profiler kernel name prefix -> library timing name
-    "void k_sketch_tiles<0, 0>": "sketch_tiles",
-    "void k_sketch_tiles<0, 1>": "sketch_tiles.compact",
+    "void k_sketch_tiles<0, 0": "sketch_tiles",          # (any k: the third template argument is the folded-in k-mer size)
+    "void k_sketch_tiles<0, 1": "sketch_tiles.compact",
     "k_msd_local(": "msd_local",
     "void k_msd_scatter<256>": "msd_scatter.level1",
     "void k_msd_scatter<512>": "msd_scatter.level2",
+    "void k_msd_scatter<1024>": "msd_scatter.level2",
     "k_bucket_scatter": "bucket_scatter",
     "void k_radix_scatter<unsigned int, 1>": "radix_scatter.qpart",
     "void k_radix_hist<1>": "radix_hist.qpart",
     "k_join_buckets": "join_buckets",
+    "k_join_sparse": "join_buckets",
     "void k_radix_scatter<unsigned long, 0>": "radix_scatter.index",
 }
 
