@@ -87,6 +87,7 @@ struct sk_args {
     u32 c_div, c_rcp; // compacting variant: bucket space is positions / c_div (c_rcp = ceil(2^32 / c_div))
     u64 out_cap;   // capacity of out_hash / out_abund (MODE 0): writes beyond it are dropped and the host repeats larger
     u32 use_ticket; // tile ids from the atomic ticket (1) or from blockIdx.x (0)
+    u32 debug_qcap;      // diagnostics (KS_DEBUG_QCAP): capacity of the bucket lists of phase 3 (0 = what fits)
     u32 debug_skip_tile; // diagnostics (KS_DEBUG_LOOKBACK_SKIP): this tile never publishes — its successors' spins really expire
     u32 le_cap;    // a sequence whose LOCAL end lies beyond this is not this launch's business
     u32 max_len_tile; // ... nor is one longer than this (packed tiles: PK_MAX_LEN, so that "long" means the same everywhere)
@@ -634,8 +635,9 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     u16 *qb = (u16 *)((u32 *)res_w + q_skip);
     u16 *q3 = qb + SK_QB_CAP;
     const u32 q_ents = ((SK_TILE + SK_PAD) / 4 - q_skip) * 2 - SK_QB_CAP;
-    const u32 q3cap = q_ents * 2 / 5, q2cap = q_ents - q3cap;
+    u32 q3cap = q_ents * 2 / 5, q2cap = q_ents - q3cap;
     u16 *q2 = q3 + q3cap;
+    if (A.debug_qcap) { q2cap = q2cap < A.debug_qcap ? q2cap : A.debug_qcap; q3cap = q3cap < A.debug_qcap ? q3cap : A.debug_qcap; } // (tests: full lists)
     u32 ovf = 0; // my buckets that found no room in a list (bit layout of the class masks below): I put them in order myself
     {
         const uint4 w4 = *(const uint4 *)&cnt[q0 >> 1]; // 8 consecutive 16-bit counters
@@ -1841,6 +1843,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         }
         A.lut = ctx->d_lut + 256 * p->moltype;
         A.upper_only = p->moltype == KS_PROTEIN ? 1u : 0u;
+        if (const char *f = ks_dbg(ctx, KS_DBG_QCAP)) A.debug_qcap = (u32)atoi(f);
         A.counts = counts;
         A.span = SK_TILE; A.c_div = 1; A.c_rcp = 0; A.out_cap = out_cap; A.max_len_tile = 0xffffffffu; A.R = 1;
         A.ticket = ticket; A.total_out = d_stats + 23;

@@ -120,6 +120,50 @@ def test_sketch_ragged_and_edge_inputs(ctx):
         assert_sketch_parity(ctx, res, offs, k, scaled, mol)
 
 
+def test_sketch_sort_phases_on_repeats_crowded_buckets_and_tiny_sequences(monkeypatch):
+    """The tile kernel puts multi-hash buckets in order in place (pairs, buckets of 3 .. 32, larger ones by the whole workgroup),
+    counts repeats while it does, and reads the sorted run back position-major (sequence lookup from register-held boundaries,
+    a table walk when a wave holds more than 8 boundaries, a head bitmap when a tile holds more sequences than its LDS tables).
+    Inputs that reach every one of those paths, plain and compacting, with and without postings; KS_DEBUG_QCAP = full lists."""
+    rng = np.random.default_rng(77)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    rnd = lambda n: bytes(rng.choice(aa, size=int(n)).tolist())
+    unit = rnd(40)
+    seqs = [b"A" * 3500, b"AC" * 1800, rnd(13) * 250, unit * 60, b"W" * 70, rnd(400), b"LIVING" * 500]   # repeats: buckets far beyond 32
+    seqs += [rnd(n) for n in rng.integers(150, 600, 40)]                                                  # ordinary neighbours
+    seqs += [rnd(rng.integers(5, 14)) for _ in range(1500)]                                               # > 254 sequences per tile
+    seqs += [b"GGGGGGGGGGGGGG"] * 700 + [b"ACACACACACACACAC"] * 500                                       # ... with repeats inside them
+    seqs += [rnd(n) for n in rng.integers(20, 60, 600)]                                                   # > 8 boundaries per wave
+    seqs += [unit[:25] * 3] * 300
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    # ... and an unmixed run of tiny sequences, so that whole tiles hold ~400 of them (more than the LDS tables take), repeats included
+    seqs += [rnd(rng.integers(5, 14)) if i % 5 else b"GGGGGGGGGGGG" for i in range(3000)]
+    res, offs = ks.pack(seqs)
+    t_res, t_off = ks.pack(seqs[::3])
+    c = ks.Context(0, follow_debug_env=True)
+    try:
+        for qcap in (None, "3"):
+            if qcap:
+                monkeypatch.setenv("KS_DEBUG_QCAP", qcap)
+            for k, scaled, mol in ((5, 1, "protein"), (10, 1, "protein"), (7, 1, "hp"), (12, 1, "dayhoff"), (10, 2, "dayhoff"), (24, 5, "hp"),
+                                   (16, 5, "dayhoff"), (6, 3, "hp")):
+                assert_sketch_parity(c, res, offs, k, scaled, mol)
+                # the same batch as a query batch (postings emitted by the tile kernel): same sketches, same hits as the plain path
+                T = c.sketch_batch(t_res, t_off, k, scaled, mol)
+                ix = c.index_build(T)
+                d_res, d_off = c.to_device(res), c.to_device(offs)
+                Q = c.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(offs) - 1, len(res))
+                P = c.sketch_batch(res, offs, k, scaled, mol)
+                for g, w in zip(Q.to_host(), P.to_host()):
+                    assert np.array_equal(g, w)
+                for g, w in zip(c.search(ix, Q).to_host(), c.search(ix, P).to_host()):
+                    assert np.array_equal(g, w)
+        monkeypatch.delenv("KS_DEBUG_QCAP")
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("lo,hi,n", [(1, 60, 30000), (20, 128, 20000), (200, 300, 8000), (600, 900, 4000),
                                      (1000, 1600, 2500), (1500, 4080, 1200), (1, 4200, 1500)])
 def test_sketch_every_tile_stride(ctx, lo, hi, n):
