@@ -697,10 +697,17 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
 #pragma unroll
     for (int i = 0; i < SK_E; i++)
         if (bo[i] != 0xffffffffu) tmp[bstart(SK_BO_B(bo[i])) + SK_BO_O(bo[i])] = h[i];
-    if (B.in_lds)
+    if (B.in_lds) {
         for (u32 i = tid; i <= ns; i += SK_THREADS) // (first bucket of a sequence: its local start, or the compacted base of the bucket table)
             dseq[i] = (u16)(i == ns ? n_kept : bstart(CMP ? ((const uint2 *)res_w)[i].x : loff[i]));
-    if (MODE == 0) // a deferred (medium / long) sequence that starts inside this tile (at most one: the last): its unique count is known
+    } else { // (rare: more sequences than the LDS tables hold) the positions at which a run starts, as a bitmap for phase 6
+        for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
+            const u32 ls = B.at(s);
+            const u32 d = ls <= SK_TILE ? bstart(ls) : n_kept;
+            if (d < n_kept) atomicOr(&flagbits[d >> 5], 1u << (d & 31));
+        }
+    }
+    if (MODE == 0) { // a deferred (medium / long) sequence that starts inside this tile (at most one: the last): its unique count is known
         for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
             const u32 ls = B.at(s), le = B.at(s + 1);
             if (le > A.le_cap || le - ls > A.max_len_tile) {
@@ -708,12 +715,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                 if (e < 4) { ext_seq[e] = s; ext_cnt[e] = A.counts[s]; ext_d[e] = 0; }
             }
         }
-    else // (rare: more sequences than the LDS tables hold) the positions at which a run starts, as a bitmap for phase 6
-        for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
-            const u32 ls = B.at(s);
-            const u32 d = ls <= SK_TILE ? bstart(ls) : n_kept;
-            if (d < n_kept) atomicOr(&flagbits[d >> 5], 1u << (d & 31));
-        }
+    }
     __syncthreads();
 
     SK_STAMP_AT(4);

@@ -139,13 +139,17 @@ def test_sketch_sort_phases_on_repeats_crowded_buckets_and_tiny_sequences(monkey
     seqs = [seqs[i] for i in order]
     # ... and an unmixed run of tiny sequences, so that whole tiles hold ~400 of them (more than the LDS tables take), repeats included
     seqs += [rnd(rng.integers(5, 14)) if i % 5 else b"GGGGGGGGGGGG" for i in range(3000)]
+    # ... and NEIGHBOURING tiny sequences that share hashes (equal hashes of different sequences are adjacent in the sorted tile)
+    seqs += [b"LLLSLLLLLS"[:int(n)] for n in rng.integers(5, 11, 2500)] + [b"CACCACACCAA", b"CACCAAA"] * 400
     res, offs = ks.pack(seqs)
     t_res, t_off = ks.pack(seqs[::3])
     c = ks.Context(0, follow_debug_env=True)
     try:
-        for qcap in (None, "3"):
-            if qcap:
-                monkeypatch.setenv("KS_DEBUG_QCAP", qcap)
+        # (packed tiles of a batch this small hold <= 64 sequences: fixed-stride tiles — KS_DEBUG_NO_PACK — are what puts
+        # several hundred tiny sequences into one tile here; a 1M-protein batch packs up to 1024 per tile)
+        for qcap, nopack in ((None, False), ("3", False), (None, True), ("3", True)):
+            monkeypatch.setenv("KS_DEBUG_QCAP", qcap) if qcap else monkeypatch.delenv("KS_DEBUG_QCAP", raising=False)
+            monkeypatch.setenv("KS_DEBUG_NO_PACK", "1") if nopack else monkeypatch.delenv("KS_DEBUG_NO_PACK", raising=False)
             for k, scaled, mol in ((5, 1, "protein"), (10, 1, "protein"), (7, 1, "hp"), (12, 1, "dayhoff"), (10, 2, "dayhoff"), (24, 5, "hp"),
                                    (16, 5, "dayhoff"), (6, 3, "hp")):
                 assert_sketch_parity(c, res, offs, k, scaled, mol)
@@ -159,7 +163,8 @@ def test_sketch_sort_phases_on_repeats_crowded_buckets_and_tiny_sequences(monkey
                     assert np.array_equal(g, w)
                 for g, w in zip(c.search(ix, Q).to_host(), c.search(ix, P).to_host()):
                     assert np.array_equal(g, w)
-        monkeypatch.delenv("KS_DEBUG_QCAP")
+        monkeypatch.delenv("KS_DEBUG_QCAP", raising=False)
+        monkeypatch.delenv("KS_DEBUG_NO_PACK", raising=False)
     finally:
         c.close()
 

@@ -1,11 +1,14 @@
 mkdir -p gpurun_out
-run() { name=$1; shift; env "$@" timeout -k 10 500 python tools/fuzz_parity.py --cases 350 --seed $SEED > gpurun_out/r2_fz_$name.log 2>&1; echo "$name rc=$? $(tail -1 gpurun_out/r2_fz_$name.log)"; }
-SEED=101 run default A=1
-SEED=102 run fp_staged KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=0
-SEED=103 run fp_sparse KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=1
-SEED=104 run fp_sparse_segs_coarse KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=1 KS_DEBUG_JOIN_SEGS=1 KS_DEBUG_FP_COARSEN=18
-SEED=105 run fp_staged_segs_coarse KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=0 KS_DEBUG_JOIN_SEGS=1 KS_DEBUG_FP_COARSEN=10
-SEED=106 run rows_ticket_planless KS_DEBUG_ROWS_TICKET=1 KS_DEBUG_NO_PLAN=1
-SEED=107 run nocompact_nopack KS_DEBUG_NO_COMPACT=1 KS_DEBUG_NO_PACK=1
-SEED=108 run lsd_paths KS_DEBUG_PAIRS_LSD=1 KS_DEBUG_INDEX_LSD=1 KS_DEBUG_UNPACKED_PAIRS=1
-SEED=109 timeout -k 10 600 python tools/fuzz_parity.py --big --cases 20 --seed 109 > gpurun_out/r2_fz_big.log 2>&1; echo "big rc=$? $(tail -1 gpurun_out/r2_fz_big.log)"
+run() { name=$1; shift; env "$@" timeout -k 10 500 python tools/fuzz_parity.py --cases 350 --seed $SEED > gpurun_out/r3_fz_$name.log 2>&1; echo "$name rc=$? $(tail -1 gpurun_out/r3_fz_$name.log)"; }
+SEED=301 run default A=1
+SEED=302 run fp_staged KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=0
+SEED=303 run fp_sparse KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=1
+SEED=304 run fp_sparse_segs_coarse KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=1 KS_DEBUG_JOIN_SEGS=1 KS_DEBUG_FP_COARSEN=18
+SEED=305 run fp_staged_segs_coarse KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=0 KS_DEBUG_JOIN_SEGS=1 KS_DEBUG_FP_COARSEN=10
+SEED=306 run rows_ticket_planless KS_DEBUG_ROWS_TICKET=1 KS_DEBUG_NO_PLAN=1
+SEED=307 run nocompact_nopack KS_DEBUG_NO_COMPACT=1 KS_DEBUG_NO_PACK=1
+SEED=308 run lsd_paths KS_DEBUG_PAIRS_LSD=1 KS_DEBUG_INDEX_LSD=1 KS_DEBUG_UNPACKED_PAIRS=1
+SEED=310 run full_lists KS_DEBUG_QCAP=2
+SEED=311 run nopack KS_DEBUG_NO_PACK=1
+SEED=312 run nopack_full_lists KS_DEBUG_NO_PACK=1 KS_DEBUG_QCAP=1
+SEED=309 timeout -k 10 600 python tools/fuzz_parity.py --big --cases 20 --seed 309 > gpurun_out/r3_fz_big.log 2>&1; echo "big rc=$? $(tail -1 gpurun_out/r3_fz_big.log)"
