@@ -128,6 +128,24 @@ def run_big(cases: int, seed: int) -> int:
         t_res, t_off = synth.proteome(nt, stream=5000 + case, hi=int(rng.choice([300, 3000, 9000])))
         q_res, q_off = synth.queries(nq, t_res, t_off, stream=6000 + case, frac_related=float(rng.choice([0.0, 0.2, 0.9])))
         tag = f"big case {case}: k={k} scaled={scaled} {mol} nt={nt} nq={nq}"
+        if case % 4 == 3:
+            # a big batch of PEPTIDES (>= 262,144 sequences: packed tiles then take up to 1024 sequences each — more than a
+            # tile's LDS tables hold — and neighbouring peptides share k-mers)
+            n = int(rng.integers(270000, 400000))
+            lens = rng.integers(0, int(rng.choice([12, 20, 40])), n).astype(np.uint64)
+            offs = np.zeros(n + 1, np.uint64)
+            np.cumsum(lens, out=offs[1:])
+            alpha = np.frombuffer(ALPHABETS[int(rng.integers(0, len(ALPHABETS)))], np.uint8)
+            res = rng.choice(alpha, size=int(offs[-1])).astype(np.uint8)
+            kk = int(rng.choice([2, 3, 5, 7]))
+            tag = f"big case {case}: peptides k={kk} scaled={scaled} {mol} n={n}"
+            try:
+                got = ctx.sketch_batch(res, offs, kk, scaled, mol).to_host()
+                if not all(np.array_equal(g, w) for g, w in zip(got, oracle.sketch_batch(res, offs, kk, scaled, mol, n_threads=16))):
+                    print("SKETCH MISMATCH", tag); bad += 1
+            except Exception as e:  # noqa: BLE001
+                print("ERROR", tag, repr(e)); bad += 1
+            continue
         try:
             T = ctx.sketch_batch(t_res, t_off, k, scaled, mol)
             if not all(np.array_equal(g, w) for g, w in zip(T.to_host(), oracle.sketch_batch(t_res, t_off, k, scaled, mol, n_threads=16))):
