@@ -302,7 +302,9 @@ def run_queries_sharded(args, env, ks, synth, ksd):
         # scratch passes of the search (not §8(d) bytes): what each launch has to move by design
         "bucket_scatter": 24 * n_q_hashes,                                # 12 B posting in, 12 B out
         "radix_hist.qpart": 8 * n_q_hashes,
-        "join_buckets": 12 * n_q_hashes + 12 * n_t_postings + 8 * n_pairs,  # postings read once + one 8-B record per match
+        # query postings read once + the index side once — 4-byte fingerprints for big indexes (>= 2^15 join buckets: the
+        # 16-byte posting is fetched per candidate match only), 12-byte postings otherwise — + one 8-B record per match
+        "join_buckets": 12 * n_q_hashes + ((4 * n_t_postings + 16 * n_pairs) if (n_t_postings >> 14) > 3072 else 12 * n_t_postings) + 8 * n_pairs,
     }
     traffic_tab, traffic_src = load_traffic(profile_key(args, n_q))
 
@@ -596,7 +598,8 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
     step_bytes = sketch_bytes + 12 * stats[0] + 12 * n_t_postings + 16 * stats[1]
     traffic_tab, traffic_src = load_traffic("c5_200k_hp_k24_s5" if (world == 1 and (n_prot, k, scaled, mol) == (200_000, 24, 5, "hp")) else None)
     dom = max(timing_all.items(), key=lambda kv: kv[1][1])[0] if timing_all else None
-    design = {"sketch_tiles": sketch_bytes, "bucket_scatter": 24 * stats[0], "join_buckets": 12 * stats[0] + 12 * n_t_postings + 8 * stats[2],
+    design = {"sketch_tiles": sketch_bytes, "bucket_scatter": 24 * stats[0],
+              "join_buckets": 12 * stats[0] + ((4 * n_t_postings + 16 * stats[2]) if (n_t_postings >> 14) > 3072 else 12 * n_t_postings) + 8 * stats[2],
               "pair_rows": 8 * stats[2] + 20 * stats[1], "msd_local": 16 * stats[2], "msd_scatter": 16 * stats[2], "msd_hist": 8 * stats[2]}
     roofline = None
     if dom:
