@@ -45,7 +45,7 @@ struct ks_copy_engine; // ks_copy.hip: pinned staging + host copy threads for pa
     X(STAGED_H2D) X(PLAIN_COPIES) X(PAIRS_LSD) X(MSD_LDS_CAP) X(SCAN_3PASS) X(INDEX_LSD) X(JOIN_FP) X(FP_COARSEN)        \
     X(PAIR_LIMIT) X(PBITS_MAX) X(UNPACKED_PAIRS) X(ONE_CURSOR) X(JOIN_SEGS) X(JOIN_SEG_CAP) X(JOIN_SPARSE) X(UNFUSED_ROWS) \
     X(NO_ROWS_HINT) X(ROWS_TICKET) X(FORCE_ROWS_TICKET_RETRY) X(FORCE_TICKET_RETRY) X(NO_PLAN) X(NO_COMPACT) X(SPAN)      \
-    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP)
+    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP) X(SYNC_API)
 enum ks_dbg_id {
 #define KS_DBG_ENUM(n) KS_DBG_##n,
     KS_DBG_LIST(KS_DBG_ENUM)
@@ -99,7 +99,15 @@ struct ks_ctx {
     u32 scan_ticket_base = 0; // value the device counter will have when the next scan starts
     // encode LUTs (3 x 256 bytes) in device memory
     u8 *d_lut = nullptr;
+    // ks_stream_wait: a pinned host word the stream's last kernel stamps, polled by the host (see ks_ctx.hip)
+    unsigned long long *h_flag = nullptr;
+    unsigned long long wait_seq = 0;
 };
+
+// The host waits for everything queued on the context's stream (what hipStreamSynchronize does) by polling a pinned word
+// that a one-thread kernel at the end of the queue stamps: the wake-up of a blocking synchronisation costs 10 - 25 us of idle
+// queue on this runtime, and a sketch + search step waits three times.  KS_DEBUG_SYNC_API = the runtime's call instead.
+int ks_stream_wait(ks_ctx *ctx);
 
 // returns nullptr and sets ctx->err on failure
 void *ks_pool_alloc(ks_ctx *ctx, size_t bytes);

@@ -176,6 +176,8 @@ extern "C" int ks_ctx_create(int device, void *hip_stream, ks_ctx **out) {
         ctx->own_stream = true;
     }
     if (hipHostMalloc((void **)&ctx->h_pin, 128 * sizeof(u64)) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
+    if (hipHostMalloc((void **)&ctx->h_flag, 64) != hipSuccess) { (void)hipGetLastError(); ctx->h_flag = nullptr; } // (ks_stream_wait falls back to the API)
+    else *ctx->h_flag = 0;
     if (hipMalloc((void **)&ctx->d_lut, 3 * 256) != hipSuccess) { delete ctx; return KS_ERR_OOM; }
     u8 lut[768];
     build_luts(lut);
@@ -194,6 +196,7 @@ extern "C" void ks_ctx_destroy(ks_ctx *ctx) {
     for (auto &b : ctx->pool) (void)hipFree(b.ptr);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
     if (ctx->scan_ring) (void)hipFree(ctx->scan_ring);
     if (ctx->scan_ticket) (void)hipFree(ctx->scan_ticket);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -274,6 +277,38 @@ extern "C" int ks_dev_download(ks_ctx *ctx, void *dst, const void *src, uint64_t
     KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KS_OK;
     });
+}
+
+// ---- ks_stream_wait -------------------------------------------------------------------------
+__global__ void k_host_stamp(unsigned long long *flag, unsigned long long seq) {
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+int ks_stream_wait(ks_ctx *ctx) {
+    if (!ctx->h_flag || ks_dbg(ctx, KS_DBG_SYNC_API)) {
+        KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return KS_OK;
+    }
+    const unsigned long long seq = ++ctx->wait_seq;
+    hipLaunchKernelGGL(k_host_stamp, dim3(1), dim3(1), 0, ctx->stream, ctx->h_flag, seq);
+    if (hipGetLastError() != hipSuccess) { KS_HIP(ctx, hipStreamSynchronize(ctx->stream)); return KS_OK; }
+    // (the stamp arrives behind every copy and kernel queued before it; a stream that has failed never stamps: the
+    // runtime is asked now and then, and after a while it is simply left to the blocking call)
+    for (unsigned spins = 1;; spins++) {
+        if (__atomic_load_n(ctx->h_flag, __ATOMIC_ACQUIRE) == seq) return KS_OK;
+        if ((spins & 0xfffu) == 0) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) { // everything has run: the stamp is in host memory by now
+                if (__atomic_load_n(ctx->h_flag, __ATOMIC_ACQUIRE) == seq) return KS_OK;
+                KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                return KS_OK;
+            }
+            if (q != hipErrorNotReady) return ks_fail(ctx, KS_ERR_HIP, "stream failed: %s", hipGetErrorString(q));
+            if (spins > (1u << 26)) { KS_HIP(ctx, hipStreamSynchronize(ctx->stream)); return KS_OK; } // (seconds: a long queue)
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
 }
 
 // ---- pool ---------------------------------------------------------------------------------

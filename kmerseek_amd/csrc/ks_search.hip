@@ -1269,7 +1269,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 else
                     SE_HIP(hipMemcpy2DAsync(ctx->h_pin, 2 * sizeof(u64), cursor, (size_t)JN_CUR_STRIDE * sizeof(u64), 2 * sizeof(u64), JN_SEGS,
                                             hipMemcpyDeviceToHost, ctx->stream));
-                SE_HIP(hipStreamSynchronize(ctx->stream));
+                SE_CHECK(ks_stream_wait(ctx));
                 n_pairs = 0;
                 u64 seg_max = 0;
                 for (u32 s_ = 0; s_ < n_segs; s_++) {
@@ -1390,7 +1390,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             SE_HIP(hipGetLastError());
             if (!fused) SE_HIP(hipMemcpyAsync(ctx->h_pin + 2, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
             SE_CHECK(ks_scan_status_fetch(ctx));
-            SE_HIP(hipStreamSynchronize(ctx->stream));
+            SE_CHECK(ks_stream_wait(ctx));
             SE_CHECK(ks_scan_status_check(ctx));
             bool gave_up = fused && ((u32 *)(ctx->h_pin + 1))[1] != 0;
             if (fused && ks_dbg(ctx, KS_DBG_FORCE_ROWS_TICKET_RETRY) && !ctx->rows_use_ticket) gave_up = true; // (tests)

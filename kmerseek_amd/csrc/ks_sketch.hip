@@ -1740,7 +1740,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         SK_HIPCHECK(hipMemsetAsync(S->d_offsets, 0, sizeof(u64), ctx->stream));
         SK_CHECK(ks_alloc(ctx, &S->d_hashes, 1));
         SK_CHECK(ks_alloc(ctx, &S->d_abunds, 1));
-        SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
+        SK_CHECK(ks_stream_wait(ctx));
         *out = S;
         return KS_OK;
     }
@@ -1786,7 +1786,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             // no upper bound on the sequence length from the caller: the plan (tile stride, deferred sequences, slab size)
             // comes from the batch itself, at the price of one device -> host round trip before the tiles are launched
             SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, SK_CTL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-            SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
+            SK_CHECK(ks_stream_wait(ctx));
             win_bound = ctx->h_pin[0];
             if (packed) pk_n_tiles = *(u32 *)(ctx->h_pin + 22);
             if (ctx->h_pin[1] > 0xfffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "sequence longer than 2^32 residues"); goto done; }
@@ -1996,7 +1996,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             SK_HIPCHECK(hipGetLastError());
             // total + look-back error flag to the host
             SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, SK_CTL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-            SK_HIPCHECK(hipStreamSynchronize(ctx->stream));
+            SK_CHECK(ks_stream_wait(ctx));
             u32 &status_w = ((u32 *)(ctx->h_pin + 20))[1];
             if (attempt == 0 && !A.use_ticket && ks_dbg(ctx, KS_DBG_FORCE_TICKET_RETRY)) status_w |= 1u; // exercises the repeat
             if (!(status_w & 1u) || A.use_ticket) break;
