@@ -55,6 +55,16 @@ def _worker(rank, world, port, mode, out_dir):
             hits = ksd.search_queries_sharded(fn, q_res, q_off, t_res, t_off)
         else:
             hits = ksd.search_index_sharded(fn, q_res, q_off, t_res, t_off)
+            # the two-phase form of the same exchange (begin: pack + start the collective, finish: complete it): on host
+            # columns it completes at once, with the same rows
+            s0, s1 = ksd.shard_by_residues(t_off, world)[rank]
+            local = fn(q_res, q_off, *ksd.slice_batch(t_res, t_off, s0, s1))
+            pend = ksd.begin_all_gather_hits_device(local, tid_base=s0, sharded="index", order="qid",
+                                                    id_counts=(len(q_off) - 1, len(t_off) - 1))
+            got = pend.finish()
+            assert got is pend.finish()  # (idempotent)
+            for g, w in zip(got, hits):
+                assert np.array_equal(g.cpu().numpy().view(w.dtype), w)
         np.savez(os.path.join(out_dir, f"hits_{mode}_{rank}.npz"), qid=hits[0], tid=hits[1], isect=hits[2], nw=hits[3],
                  t_res=t_res, t_off=t_off, q_res=q_res, q_off=q_off)
     finally:
