@@ -15,14 +15,18 @@
 //   * Per-sequence "sort + unique + count" without a comparison sort: murmur output is uniform, so a
 //     kept hash goes to bucket  seq_start + floor(h / max_hash * n_windows)  (monotone in h; ~1 element per
 //     bucket).  LDS atomics count buckets and hand out arrival slots, one block scan turns counts into
-//     starts, elements are ranked inside their (tiny) bucket by comparison.  Equal hashes meet in one
-//     bucket: the first arrival is the representative and carries the abundance.
-//   * Representatives are compacted through LDS and leave as one contiguous run per tile; a per-sequence
-//     count + scan + gather builds the final CSR.
+//     starts, the hashes are scattered into bucket order; the buckets that hold more than one hash are LISTED by the
+//     thread that scans them and put in order in place (a pair: one compare; a few: insertion sort; many — repeats of
+//     a low-complexity sequence —: ranked by the whole workgroup).  Equal hashes of a sequence share a bucket, so the
+//     repeats are counted on the way: the tile's distinct count is known before anything is read back.
+//   * Tiles with repeats (or with postings to emit) read the sorted run back position-major: representative flags,
+//     abundances and distinct ranks from bitmaps; the others write their sorted run as it stands.  A decoupled
+//     look-back over the tiles' distinct counts gives the tile its place in the final CSR: one coalesced stream out.
 //   * A sequence that starts inside a tile's residue range but does not END inside the tile's LDS window (at most
 //     one per tile, the last) is deferred: if it fits a tile on its own ("medium") it gets one in a second launch of
 //     the same kernel; longer ones take the same algorithm with its arrays in a global scratch slab (k_sketch_long),
-//     one workgroup per sequence.
+//     one workgroup per sequence.  (Packed tiles — the plain variant — hold whole sequences: only sequences longer than a
+//     tile go to the slab path.)
 #include "ks_device.h"
 
 #ifndef SK_THREADS
