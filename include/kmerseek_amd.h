@@ -178,7 +178,9 @@ int ks_sketch_queries_device(ks_ctx *ctx, const ks_index *index, const uint8_t *
 uint32_t ks_sketches_n_seqs(const ks_sketches *s);
 uint64_t ks_sketches_n_hashes(const ks_sketches *s);
 uint64_t ks_sketches_n_windows(const ks_sketches *s); /* k-mer windows hashed to build it */
-int ks_sketches_has_postings(const ks_sketches *s);   /* 1 if ks_sketch_queries_device's partitioned postings are attached */
+/* != 0 if ks_sketch_queries_device's partitioned postings are attached: 1 = 12-byte postings (hash, sequence id),
+ * 2 = 10-byte postings (the fingerprint join of big indexes at scaled = 1: 8 hash bits are implied by the region) */
+int ks_sketches_has_postings(const ks_sketches *s);
 void ks_sketches_params(const ks_sketches *s, ks_params *out);
 /* device pointers (valid until ks_sketches_free): offsets u64[n+1], hashes u64[], abund u32[] */
 const uint64_t *ks_sketches_device_offsets(const ks_sketches *s);

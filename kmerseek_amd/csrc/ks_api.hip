@@ -11,7 +11,7 @@ extern "C" int ks_sketch_batch_device(ks_ctx *ctx, const uint8_t *d_residues, co
     return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
-    return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, params, 0, out);
+    return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, params, 0, 0, out);
     });
 }
 
@@ -22,7 +22,7 @@ extern "C" int ks_sketch_queries_device(ks_ctx *ctx, const ks_index *index, cons
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!index || !out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, &index->params,
-                                 index->pbits, out);
+                                 index->pbits, (index->fp_layout && index->fp_shift == 32 - index->pbits) ? 1 : 0, out);
     });
 }
 
@@ -60,7 +60,7 @@ extern "C" int ks_sketch_batch(ks_ctx *ctx, const uint8_t *residues, const uint6
     u64 n_res = 0;
     u32 max_len = 0;
     int st = upload_batch(ctx, residues, seq_offsets, n_seqs, &d_res, &d_offs, &n_res, &max_len);
-    if (st == KS_OK) st = ks_sketch_device_impl(ctx, d_res, d_offs, n_seqs, n_res, max_len, params, 0, out);
+    if (st == KS_OK) st = ks_sketch_device_impl(ctx, d_res, d_offs, n_seqs, n_res, max_len, params, 0, 0, out);
     (void)hipStreamSynchronize(ctx->stream);
     ks_pool_free(ctx, d_res);
     ks_pool_free(ctx, d_offs);
@@ -72,7 +72,7 @@ extern "C" uint32_t ks_sketches_n_seqs(const ks_sketches *s) { return s ? s->n_s
 extern "C" uint64_t ks_sketches_n_hashes(const ks_sketches *s) { return s ? s->n_hashes : 0; }
 extern "C" uint64_t ks_sketches_n_windows(const ks_sketches *s) { return s ? s->n_windows : 0; }
 extern "C" int ks_sketches_has_postings(const ks_sketches *s) {
-    return ks_guard(nullptr, [&]() -> int { return (s && s->part_keys) ? 1 : 0; 
+    return ks_guard(nullptr, [&]() -> int { return (s && s->part_keys) ? (s->part_s ? 2 : 1) : 0;
     });
 }
 extern "C" void ks_sketches_params(const ks_sketches *s, ks_params *out) { if (s && out) *out = s->params; }

@@ -45,7 +45,7 @@ struct ks_copy_engine; // ks_copy.hip: pinned staging + host copy threads for pa
     X(STAGED_H2D) X(PLAIN_COPIES) X(PAIRS_LSD) X(MSD_LDS_CAP) X(SCAN_3PASS) X(INDEX_LSD) X(JOIN_FP) X(FP_COARSEN)        \
     X(PAIR_LIMIT) X(PBITS_MAX) X(UNPACKED_PAIRS) X(ONE_CURSOR) X(JOIN_SEGS) X(JOIN_SEG_CAP) X(JOIN_SPARSE) X(UNFUSED_ROWS) \
     X(NO_ROWS_HINT) X(ROWS_TICKET) X(FORCE_ROWS_TICKET_RETRY) X(FORCE_TICKET_RETRY) X(NO_PLAN) X(NO_COMPACT) X(SPAN)      \
-    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP) X(SYNC_API)
+    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP) X(SYNC_API) X(POSTINGS12)
 enum ks_dbg_id {
 #define KS_DBG_ENUM(n) KS_DBG_##n,
     KS_DBG_LIST(KS_DBG_ENUM)
@@ -195,6 +195,11 @@ struct ks_sketches {
     // each region is split into 2^part_sub_shift sub-regions, one per XCD of the sketch launch (segment r << shift | x
     // at (r << shift | x) * part_cap, part_len likewise): slices that are neighbours in memory were written through ONE L2
     u32 part_sub_shift;
+    // part_s != 0: 10-byte postings.  Inside region r the 8 hash bits [part_s, part_s + 8) ARE r (scaled = 1: the join
+    // prefix is a bit field of the hash), so the key column carries the low 8 bits of the sequence id there and part_vals is
+    // a u16 column with the rest (sequence ids < 2^24): 10 instead of 12 bytes through the sketch write, the bucket scatter
+    // (in and out) and the join's read.
+    u32 part_s;
 };
 
 // one index posting as the join fetches it for a candidate match: one 16-byte load
@@ -282,7 +287,7 @@ int ks_radix_sort_keys(ks_ctx *ctx, int tag, const u64 *keys_in, u64 *ka, u64 *k
 // UTCL1 translation misses per launch with the digit-major order, 0.02 M with this one — same run time, though)
 #define KS_BSLOT(d, r, n_hi) ((r) * (n_hi) + (d))
 int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, const ks_rs_segments *seg, int shift,
-                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status, u32 n_hi);
+                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status, u32 n_hi, int vals16);
 // index build in three passes (two partition passes + in-LDS bucket sort); *overflowed = 1: use the LSD sort instead
 int ks_index_sort_partitioned(ks_ctx *ctx, const u64 *keys_in, const u64 *vals_in, u64 n, u64 max_hash, u64 *okeys, u32 *otids,
                               u32 *oabunds, u32 *d_max_abund, int *overflowed);
@@ -296,7 +301,7 @@ int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_
 // ---- pipelines (ks_sketch.hip, ks_search.hip) ----
 // part_pbits > 0: also emit postings partitioned for a join on the top part_pbits hash bits
 int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,
-                          u32 max_seq_len, const ks_params *p, int part_pbits, ks_sketches **out);
+                          u32 max_seq_len, const ks_params *p, int part_pbits, int part_fmt10, ks_sketches **out);
 // bits of hash prefix the join against an index of n_postings uses (buckets of ~3k index postings, <= 16)
 int ks_join_pbits(const ks_ctx *ctx, u64 n_postings);
 // multiplier of ks_join_prefix (ks_device.h) for a join on pbits prefix bits of hashes kept below max_hash

@@ -426,6 +426,8 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
 // irrelevant to the join, so the rank of a record inside its (tile, digit) group is just the return value of one LDS
 // atomic — no ballot matching, no per-wave counters.  A bucket that would overflow raises status[1] and the host
 // redoes the pass the dense (stable, histogrammed) way.
+// V16: the value column is 16 bits wide, in and out (10-byte query postings: ks_sketches::part_s)
+template <int V16>
 __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout,
                                                                         int shift, const u32 *seg_len, u64 seg_cap,
                                                                         u32 tiles_per_seg, u32 *bcur, u32 bcap,
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
         const u32 li = (u32)r * RS_THREADS + tid;
         const bool valid = li < nvalid;
         key[r] = valid ? kin[tile_base + li] : 0ULL;
-        val[r] = valid ? vin[tile_base + li] : 0u;
+        val[r] = valid ? (V16 ? (u32)((const u16 *)vin)[tile_base + li] : vin[tile_base + li]) : 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -515,7 +517,10 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < RS_IPT; i++)
-        if (gdst[i] != ~0ULL) vout[gdst[i]] = vstage[(u32)i * RS_THREADS + tid];
+        if (gdst[i] != ~0ULL) {
+            if (V16) ((u16 *)vout)[gdst[i]] = (u16)vstage[(u32)i * RS_THREADS + tid];
+            else vout[gdst[i]] = vstage[(u32)i * RS_THREADS + tid];
+        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -850,11 +855,15 @@ int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_
 
 // One pass, no histogram: segmented postings (regions by the low digit) -> 2^pbits fixed-capacity buckets.
 int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, const ks_rs_segments *seg, int shift,
-                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status, u32 n_hi) {
+                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status, u32 n_hi, int vals16) {
     const u32 tiles_per_seg = (u32)((seg->cap + RS_TILE - 1) / RS_TILE);
     const u32 nblocks = seg->regions * tiles_per_seg;
     ks_timer_begin(ctx, "bucket_scatter");
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in, bkeys, bvals, shift,
+    if (vals16)
+        hipLaunchKernelGGL((k_bucket_scatter<1>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in, bkeys, bvals, shift,
+                           seg->len, seg->cap, tiles_per_seg, bcur, bcap, status, pfxK, n_hi, seg->sub_shift);
+    else
+    hipLaunchKernelGGL((k_bucket_scatter<0>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in, bkeys, bvals, shift,
                        seg->len, seg->cap, tiles_per_seg, bcur, bcap, status, pfxK, n_hi, seg->sub_shift);
     ks_timer_end(ctx);
     KS_HIP(ctx, hipGetLastError());

@@ -480,12 +480,35 @@ KS_DEV void jn_confirm_slow(const ks_post *post, u32 p0, u32 c, u64 h, u32 *firs
     *first = lo; *count = lo2 - lo;
 }
 
+// Query postings as the join reads them.  12-byte form (F10 = 0): (hash u64, sequence id u32).  10-byte form (F10 = 1, see
+// ks_sketches::part_s): in join bucket b the hash bits [s, s + 8), s = 32 + fp_shift, are b's low byte, so the key column
+// carries the low 8 bits of the sequence id there and the value column is 16 bits wide.  The field sits right above the 32 bits
+// the fingerprint is made of, and every index posting of the bucket holds b's byte there: fingerprints are taken from the raw
+// word and a candidate is confirmed on the other 56 bits — the 10-byte form costs no instruction per posting, one AND per
+// candidate and one extra key read per match.
+template <int F10> struct jn_qfmt {
+    u64 keep, fill;
+    u32 s;
+    KS_DEV jn_qfmt(int fp_shift, u32 bucket)
+        : keep(F10 ? ~(0xffULL << (32 + fp_shift)) : ~0ULL), fill(F10 ? (u64)(bucket & 0xffu) << (32 + fp_shift) : 0ULL), s(32u + (u32)fp_shift) {}
+    KS_DEV u64 hash(u64 raw) const { return F10 ? ((raw & keep) | fill) : raw; }
+    // fingerprint of a raw key word inside the bucket whose first key is `base`
+    KS_DEV u32 fp(u64 raw, u64 base, int shift) const { return F10 ? (u32)((raw - base) >> shift) : jn_fingerprint(raw, base, shift); }
+    // can the raw word match anything in the bucket?  (10-byte form: a word below the base only yields a false candidate)
+    KS_DEV bool in_range(u64 raw, u64 base) const { return F10 ? true : raw >= base; }
+    KS_DEV bool same(u64 post_key, u64 raw) const { return F10 ? (((post_key ^ raw) & keep) == 0) : post_key == raw; }
+    KS_DEV u32 qid(const u64 *qk, const u32 *qv, u32 i) const {
+        return F10 ? (((u32)(qk[i] >> s) & 0xffu) | ((u32)((const u16 *)qv)[i] << 8)) : qv[i];
+    }
+};
+
 // cursor[0] = matches appended so far (keeps counting past `cap` so the host can size a retry).
 // Per round of JN_THREADS*JN_E query postings: every thread searches the staged fingerprints for its queries (LDS only);
 // the candidates of a wave — a few per cent of its queries, anywhere among a thread's JN_E slots — are LISTED in LDS
 // (query slot, index posting, full hash), so that lane k confirms and emits candidate k: one 16-byte posting fetch and one
 // qid fetch per candidate in full lanes, the confirmed ones ranked by a wave scan (segmented pair list: one reservation per
 // wave on the segment's cursor) or a block scan (one cursor: one reservation per workgroup round), contiguous stores.
+template <int F10>
 __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_join_buckets(
     const u64 *qkeys, const u32 *qids, const u32 *ifp, const ks_post *ipost, const ks_bmeta *bmeta, const u64 *q_lo, const u64 *q_hi,
     const u64 *dir_t, u64 *pair_keys, u32 *pair_vals, u64 cap, unsigned long long *cursors, u32 seg_mask, int tbits, int abits,
@@ -504,6 +527,7 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
     const u64 ts = dir_t[blockIdx.x], te = dir_t[blockIdx.x + 1];
     const ks_bmeta bm = bmeta[blockIdx.x]; // (with the directory words: one memory latency)
     if (qs == qe || ts == te) return;
+    const jn_qfmt<F10> QF(fp_shift, blockIdx.x);
     // The pair list is cut into seg_mask + 1 segments of `cap` records, each with its own cursor (JN_CUR_STRIDE words apart:
     // different memory channels): atomics on ONE address are served one at a time, ~12 ns each on this chip — 65,536 buckets
     // on one cursor are 0.8 ms of queueing whatever else the kernel does.  A bucket appends to segment (bucket mod segments).
@@ -520,7 +544,7 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
 #pragma unroll
         for (int e = 0; e < JN_E; e++) {
             const u32 i = (u32)e * JN_THREADS + tid;
-            h[e] = i < nq0 ? qkeys[qs + i] : 0;
+            h[e] = i < nq0 ? qkeys[qs + i] : 0; // (raw words: jn_qfmt)
         }
     }
     for (u64 c0 = ts; c0 < te; c0 += JN_CAP) {
@@ -564,7 +588,7 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
         for (u64 q0 = qs; q0 < qe; q0 += (u64)JN_THREADS * JN_E) {
             u32 info[JN_E]; // position | run length << 16
             const u64 *qkr = qkeys + q0;
-            const u32 *qir = qids + q0;
+            const u32 *qir = F10 ? (const u32 *)((const u16 *)qids + q0) : qids + q0; // (16-bit value column: jn_qfmt)
             const u32 nq = (u32)((qe - q0) < (u64)JN_THREADS * JN_E ? (qe - q0) : (u64)JN_THREADS * JN_E); // query postings of this round
             if (q0 != qs || c0 != ts) { // (uniform; the first round's are on their way since the top)
 #pragma unroll
@@ -585,13 +609,13 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
                 // (uniform: a bucket with few query postings — small batches, query shards of a strong-scaling run — fills
                 // only the first slots of the round, and an empty slot would cost the same directory reads and probes as a full one)
                 if ((u32)e * JN_THREADS >= nq) continue;
-                const u32 f = jn_fingerprint(h[e], kbase, fp_shift);
+                const u32 f = QF.fp(h[e], kbase, fp_shift);
                 const u32 sl = jn_slot(f, dirM);
                 const u32 d0 = ldir[sl], d1 = ldir[sl + 1];
                 // the slot holds n / JN_DIR fingerprints on average — none or one, mostly: look at them all; a slot crowded by
                 // repeats of one hash is searched
                 u32 lo = d0, c = 0;
-                if (i < nq && h[e] >= kbase) { // (a hash below the bucket's first key matches nothing)
+                if (i < nq && QF.in_range(h[e], kbase)) { // (a hash below the bucket's first key matches nothing)
                     if (d1 - d0 <= 8u) {
                         for (u32 r = d0; r < d1; r++)
                             if (lk[r] == f) { lo = c ? lo : r; c++; }
@@ -632,8 +656,8 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
                     if (k < wtotal) {
                         const u32 en = wlist[wave][k];
                         const ks_post pt = postc[en >> 13];
-                        const u32 q = qir[en & 0x1fffu];
-                        if (pt.key == wlist_h[wave][k]) { // confirmed
+                        const u32 q = QF.qid(qkr, qir, en & 0x1fffu);
+                        if (QF.same(pt.key, wlist_h[wave][k])) { // confirmed
                             const u64 ids = ((u64)q << tbits) | pt.tid; // ids packed tight: fewer sort passes
                             rk[it] = pair_vals ? ids : ((ids << abits) | pt.abund); // packed: one 8-byte record per match
                             rv[it] = pt.abund;
@@ -648,9 +672,10 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
                 for (int e = 0; e < JN_E; e++) {
                     if (!((cand >> e) & 1u)) continue;
                     u32 lo = info[e] & 0xffffu, c = info[e] >> 16;
-                    if (postc[lo].key != h[e] || postc[lo + c - 1].key != h[e]) {
+                    const u64 hh = QF.hash(h[e]);
+                    if (postc[lo].key != hh || postc[lo + c - 1].key != hh) {
                         u32 first, cnt;
-                        jn_confirm_slow(postc, lo, c, h[e], &first, &cnt);
+                        jn_confirm_slow(postc, lo, c, hh, &first, &cnt);
                         lo += first; c = cnt;
                     }
                     info[e] = lo | (c << 16);
@@ -707,7 +732,7 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
 #pragma unroll
                         for (int k = 1; k < JN_E; k++) inf = e == k ? info[k] : inf;
                         const u32 c = inf >> 16;
-                        const u32 q = qir[(u32)e * JN_THREADS + tid];
+                        const u32 q = QF.qid(qkr, qir, (u32)e * JN_THREADS + tid);
                         const u32 j0 = inf & 0xffffu;
                         for (u32 j = 0; j < c; j++, slot++) {
                             if (slot < cap) {
@@ -745,6 +770,7 @@ KS_DEV u32 js_slot(u32 f, u32 mul) { // slot of a fingerprint: the bucket's JN_D
     return j < (u32)JS_DIR - 1u ? j : (u32)JS_DIR - 1u;
 }
 static_assert(JN_DIR == 2 * JS_DIR, "js_slot halves the JN_DIR slot");
+template <int F10>
 __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_join_sparse(
     const u64 *qkeys, const u32 *qids, const u32 *ifp, const ks_post *ipost, const ks_bmeta *bmeta, const u64 *q_lo, const u64 *q_hi,
     const u64 *dir_t, u64 *pair_keys, u32 *pair_vals, u64 cap, unsigned long long *cursors, u32 seg_mask, int tbits, int abits,
@@ -761,6 +787,7 @@ __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8
     const u64 ts = dir_t[blockIdx.x], te = dir_t[blockIdx.x + 1];
     const ks_bmeta bm = bmeta[blockIdx.x];
     if (qs == qe || ts == te) return;
+    const jn_qfmt<F10> QF(fp_shift, blockIdx.x);
     const u32 seg = blockIdx.x & seg_mask;
     unsigned long long *cursor = cursors + (size_t)seg * JN_CUR_STRIDE;
     pair_keys += (u64)seg * cap;
@@ -770,13 +797,13 @@ __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8
     for (u64 q0 = qs; q0 < qe; q0 += JS_QCAP) { // slices of the bucket's queries (one, normally)
         const u32 nq = (u32)((qe - q0) < (u64)JS_QCAP ? (qe - q0) : (u64)JS_QCAP);
         const u64 *qkr = qkeys + q0;
-        const u32 *qir = qids + q0;
+        const u32 *qir = F10 ? (const u32 *)((const u16 *)qids + q0) : qids + q0; // (16-bit value column: jn_qfmt)
         // ---- the table: counting sort of the slice by fingerprint slot
         u64 h[JS_QE];
 #pragma unroll
         for (int e = 0; e < JS_QE; e++) {
             const u32 i = (u32)e * JS_THREADS + tid;
-            h[e] = i < nq ? qkr[i] : 0;
+            h[e] = i < nq ? QF.hash(qkr[i]) : 0;
         }
         for (u32 i = tid; i <= (u32)JS_DIR; i += JS_THREADS) qdir[i] = 0;
         __syncthreads();
@@ -863,7 +890,7 @@ __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8
                     if (k < wtotal) {
                         const u32 en = wlist[wave][k], r = en & 1023u;
                         const ks_post pt = postc[en >> 10];
-                        const u32 q = qir[qi[r]];
+                        const u32 q = QF.qid(qkr, qir, qi[r]);
                         if (pt.key == qh[r]) {
                             const u64 ids = ((u64)q << tbits) | pt.tid;
                             rk[it] = pair_vals ? ids : ((ids << abits) | pt.abund);
@@ -903,7 +930,7 @@ __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8
                             if (pt.key == qh[r]) {
                                 const u64 slot = atomicAdd(cursor, 1ULL);
                                 if (slot < cap) {
-                                    const u64 ids = ((u64)qir[qi[r]] << tbits) | pt.tid;
+                                    const u64 ids = ((u64)QF.qid(qkr, qir, qi[r]) << tbits) | pt.tid;
                                     if (pair_vals) { pair_keys[slot] = ids; pair_vals[slot] = pt.abund; }
                                     else pair_keys[slot] = (ids << abits) | pt.abund;
                                 }
@@ -1168,7 +1195,12 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         // (+ the join buckets' fill counts right behind it: one allocation, one memset)
         SE_CHECK(ks_alloc(ctx, (u64 **)&cursor, (size_t)JN_SEGS * JN_CUR_STRIDE + (n_buckets + 1) / 2));
         u32 *const bcur = (u32 *)(cursor + (size_t)JN_SEGS * JN_CUR_STRIDE);
-        const bool pre = q->part_keys && q->part_pbits == pbits && q->part_K == pfxK && pbits > 0;
+        const bool pre_any = q->part_keys && q->part_pbits == pbits && q->part_K == pfxK && pbits > 0;
+        // (10-byte postings are read by the bucket scatter and the fingerprint joins only: the dense fall-back starts from the
+        // CSR, and so does a search against an index they were not made for)
+        const bool f10_fits = ix->fp_layout && pbits > 8 && q->part_s == 32u + (u32)ix->fp_shift;
+        bool pre = pre_any && (q->part_s == 0 || f10_fits);
+        const bool f10 = pre && q->part_s != 0;
         u64 cap = n_q < (1u << 20) ? (1u << 20) : n_q;
         if (ctx->pair_cap_hint > cap) cap = ctx->pair_cap_hint; // a workload that matched heavily last time will again
         u64 n_pairs = 0, seg_cap = 0, seg_count[JN_SEGS];
@@ -1176,6 +1208,8 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         // way 0: histogram-free bucket scatter of the sketch kernel's regions (may overflow on skewed hashes);
         // way 1: the dense, always-correct partition
         for (int way = (pre && pbits > 8) ? 0 : 1; way < 2; way++) {
+            if (way == 1 && f10) pre = false;
+            const u32 q_s = (way == 0 && f10) ? q->part_s : 0u;
             u64 *qk = nullptr;
             u32 *qv = nullptr;
             const u64 *q_lo = nullptr, *q_hi = nullptr;
@@ -1186,7 +1220,8 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_buckets * bcap));
                 SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_buckets * bcap));
                 ks_rs_segments seg{q->part_len, q->part_cap, q->part_regions << q->part_sub_shift, q->part_sub_shift};
-                SE_CHECK(ks_bucket_scatter_u32(ctx, q->part_keys, q->part_vals, &seg, 8, pfxK, qk0, qv0, bcur, bcap, cursor, n_buckets >> 8));
+                SE_CHECK(ks_bucket_scatter_u32(ctx, q->part_keys, q->part_vals, &seg, 8, pfxK, qk0, qv0, bcur, bcap, cursor, n_buckets >> 8,
+                                               q->part_s ? 1 : 0)); // (10-byte postings stay 10 bytes: the join decodes them)
                 ks_timer_begin(ctx, "bucket_dir");
                 hipLaunchKernelGGL(k_region_dir, dim3((n_buckets + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)bcur, (u64)bcap,
                                    n_buckets, dir_q, dir_q + n_buckets, n_buckets >> 8);
@@ -1250,11 +1285,11 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 const bool sparse = ix->fp_layout && (ks_dbg(ctx, KS_DBG_JOIN_SPARSE) ? atoi(ks_dbg(ctx, KS_DBG_JOIN_SPARSE)) != 0
                                                                                      : n_q / n_buckets <= (u64)JS_QCAP * 3 / 4);
                 if (sparse)
-                    hipLaunchKernelGGL(k_join_sparse, dim3(n_buckets), dim3(JS_THREADS), 0, ctx->stream, (const u64 *)qk,
+                    hipLaunchKernelGGL(q_s ? k_join_sparse<1> : k_join_sparse<0>, dim3(n_buckets), dim3(JS_THREADS), 0, ctx->stream, (const u64 *)qk,
                                        (const u32 *)qv, (const u32 *)ix->d_fp, (const ks_post *)ix->d_post, (const ks_bmeta *)ix->d_bmeta, q_lo,
                                        q_hi, dir_t, pk0, pv0, seg_cap, cursor, n_segs - 1, tbits, abits, ix->fp_shift);
                 else if (ix->fp_layout)
-                    hipLaunchKernelGGL(k_join_buckets, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
+                    hipLaunchKernelGGL(q_s ? k_join_buckets<1> : k_join_buckets<0>, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
                                        (const u32 *)qv, (const u32 *)ix->d_fp, (const ks_post *)ix->d_post, (const ks_bmeta *)ix->d_bmeta, q_lo,
                                        q_hi, dir_t, pk0, pv0, seg_cap, cursor, n_segs - 1, tbits, abits, ix->fp_shift);
                 else

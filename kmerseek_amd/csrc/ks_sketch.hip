@@ -118,6 +118,7 @@ struct sk_args {
     u64 part_cap;
     u32 part_K, part_mask; // region = ks_join_prefix(h, part_K) & part_mask
     u32 part_kshift;       // != 0: part_K = 2^(32 - part_kshift), the prefix is a shift (sk_digit)
+    u32 part_s;            // != 0: 10-byte postings (ks_sketches::part_s): sequence id bits 0..7 ride in hash bits [part_s, part_s + 8)
     u32 part_sub_shift;    // sub-regions per region = 1 << shift; a workgroup writes sub-region blockIdx.x & (that - 1)
 };
 
@@ -1020,8 +1021,14 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             const u64 hh = tmp[i];
             const u64 at = gaddr[sk_digit(hh, A.part_K, A.part_kshift, A.part_mask)] + i;
 #ifndef SK_NO_POST_STORES // (diagnostic builds only: the kernel's time without the posting stores)
-            A.part_keys[at] = hh;
-            A.part_vals[at] = s_first + qrel[i];
+            const u32 qid = s_first + qrel[i];
+            if (A.part_s) { // (uniform) 10-byte postings
+                A.part_keys[at] = (hh & ~(0xffULL << A.part_s)) | ((u64)(qid & 0xffu) << A.part_s);
+                ((u16 *)A.part_vals)[at] = (u16)(qid >> 8);
+            } else {
+                A.part_keys[at] = hh;
+                A.part_vals[at] = qid;
+            }
 #else
             if (at == 0xffffffffffffULL) A.part_vals[0] = (u32)hh + qrel[i];
 #endif
@@ -1358,7 +1365,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
 __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u32 *n_ids_dev, u32 ids_cap, const u64 *offs, const u64 *csr, const u64 *lg_hash,
                                                     const u32 *lg_abund, u64 *hashes, u32 *abunds, u64 out_cap, u64 *part_keys,
                                                     u32 *part_vals, u32 *part_cursor, u64 part_cap, u32 part_K,
-                                                    u32 part_mask, u32 part_sub_shift, u32 *status) {
+                                                    u32 part_mask, u32 part_sub_shift, u32 *status, u32 part_s) {
     // a compacting tile that overflowed wrote no CSR offsets for its sequences (the host repeats the batch): nothing
     // here may be trusted then
     if (__hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) return;
@@ -1378,8 +1385,13 @@ __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u32 *n
             const u32 dg = ((ks_join_prefix(h, part_K) & part_mask) << part_sub_shift) | (blockIdx.x & ((1u << part_sub_shift) - 1u));
             const u64 slot = atomicAdd(&part_cursor[dg], 1u);
             if (slot < part_cap) {
-                part_keys[(u64)dg * part_cap + slot] = h;
-                part_vals[(u64)dg * part_cap + slot] = s;
+                if (part_s) {
+                    part_keys[(u64)dg * part_cap + slot] = (h & ~(0xffULL << part_s)) | ((u64)(s & 0xffu) << part_s);
+                    ((u16 *)part_vals)[(u64)dg * part_cap + slot] = (u16)(s >> 8);
+                } else {
+                    part_keys[(u64)dg * part_cap + slot] = h;
+                    part_vals[(u64)dg * part_cap + slot] = s;
+                }
             } else {
                 atomicOr(&status[1], 2u);
             }
@@ -1687,7 +1699,7 @@ __global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, 
 // nothing produced) when the attempt has to be repeated without the corresponding economy: 1 = a compacting tile
 // overflowed its LDS lists, 2 = the batch kept more hashes than the bounded output arrays hold.
 static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, u32 max_seq_len, const ks_params *p,
-                          int part_pbits, int variant, int *redo, ks_sketches **out) {
+                          int part_pbits, int part_fmt10, int variant, int *redo, ks_sketches **out) {
     ks_sketches *S = new ks_sketches();
     memset(S, 0, sizeof *S);
     S->ctx = ctx;
@@ -1875,6 +1887,10 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             A.part_keys = S->part_keys; A.part_vals = S->part_vals; A.part_cursor = S->part_len; A.part_cap = cap;
             A.part_K = S->part_K; A.part_mask = S->part_regions - 1; A.part_sub_shift = S->part_sub_shift;
             A.part_kshift = (S->part_K & (S->part_K - 1)) == 0 && S->part_K > 1 ? 32u - (u32)__builtin_ctz(S->part_K) : 0u;
+            // 10-byte postings: when the caller's join reads them (big indexes: the fingerprint joins), the digit is a bit field
+            // of the hash (scaled = 1) below a second partition level, and the sequence ids fit 24 bits
+            if (part_fmt10 && A.part_kshift && part_pbits > 8 && n_seqs < (1u << 24) && !ks_dbg(ctx, KS_DBG_POSTINGS12))
+                A.part_s = S->part_s = 32u + A.part_kshift;
         }
 
         // ---- medium / long sequences first: their unique counts feed the tile kernel's CSR prefix
@@ -1986,7 +2002,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                 hipLaunchKernelGGL(k_place_long, dim3((u32)(n_med < 1024 ? n_med : 1024)), dim3(256), 0, ctx->stream, (const u32 *)med_ids,
                                    (const u32 *)n_cls, (u32)n_med, d_offs,
                                    (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds, out_cap,
-                                   (u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u64)0, 0u, 0u, 0u, ticket);
+                                   (u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u64)0, 0u, 0u, 0u, ticket, 0u);
                 ks_timer_end(ctx);
             }
             if (n_long > 0) {
@@ -1994,7 +2010,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                 hipLaunchKernelGGL(k_place_long, dim3((u32)(n_long < 1024 ? n_long : 1024)), dim3(256), 0, ctx->stream, (const u32 *)long_ids,
                                    (const u32 *)(n_cls + 1), (u32)n_long, d_offs,
                                    (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds, out_cap,
-                                   A.part_keys, A.part_vals, A.part_cursor, A.part_cap, A.part_K, A.part_mask, A.part_sub_shift, ticket);
+                                   A.part_keys, A.part_vals, A.part_cursor, A.part_cap, A.part_K, A.part_mask, A.part_sub_shift, ticket, A.part_s);
                 ks_timer_end(ctx);
             }
             SK_HIPCHECK(hipGetLastError());
@@ -2044,7 +2060,7 @@ done:
 }
 
 int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, u32 max_seq_len,
-                          const ks_params *p, int part_pbits, ks_sketches **out) {
+                          const ks_params *p, int part_pbits, int part_fmt10, ks_sketches **out) {
     KS_TRY(ks_check_params(ctx, p));
     if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
     if (((uintptr_t)d_res & 15) != 0) return ks_fail(ctx, KS_ERR_INVALID_ARG, "d_residues must be 16-byte aligned");
@@ -2054,7 +2070,7 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     int variant = 1;
     for (int round = 0; round < 3; round++) {
         int redo = 0;
-        const int st = sketch_attempt(ctx, d_res, d_offs, n_seqs, n_res, max_seq_len, p, part_pbits, variant, &redo, out);
+        const int st = sketch_attempt(ctx, d_res, d_offs, n_seqs, n_res, max_seq_len, p, part_pbits, part_fmt10, variant, &redo, out);
         if (st != KS_OK || !redo) return st;
         if (redo == 1) { variant &= ~1; ctx->sketch_compact_fallbacks++; }
         else { variant |= 2; ctx->sketch_cap_fallbacks++; }

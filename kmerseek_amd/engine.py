@@ -396,6 +396,11 @@ class Sketches(_Owned):
     def has_postings(self) -> bool:
         return bool(self._ctx._L.ks_sketches_has_postings(self._h))
 
+    @property
+    def posting_bytes(self) -> int:
+        """Bytes per partitioned query posting: 12, 10 (big fingerprint indexes at scaled = 1) or 0 (none attached)."""
+        return (0, 12, 10)[int(self._ctx._L.ks_sketches_has_postings(self._h))]
+
     def union(self) -> "Sketches":
         """Combined sketch: sorted unique hashes of all sequences with summed abundances (one sequence)."""
         out = C.c_void_p()

@@ -412,6 +412,72 @@ def test_presorted_query_postings_equal_plain_search(ctx, k, scaled, mol, nt, nq
             assert np.array_equal(g, w)
 
 
+@pytest.mark.parametrize("sparse", ["0", "1"])
+def test_ten_byte_query_postings_equal_plain_search(ctx, monkeypatch, sparse):
+    """Against an index in the fingerprint layout at scaled = 1 (pbits > 8) the sketch kernel emits 10-byte postings (8 hash
+    bits are implied by the region: the low byte of the sequence id rides there, the rest in a 16-bit column).  Same
+    sketches and the same rows as the plain search and the oracle, in both fingerprint join kernels; sequence ids beyond
+    2^16 (more than one value of the 16-bit column... and of its high byte), medium / long sequences (their own emission
+    path) and repeated proteins (candidate runs, confirm on 56 bits) included.  KS_DEBUG_POSTINGS12 keeps the 12-byte form."""
+    monkeypatch.setenv("KS_DEBUG_JOIN_FP", "1")
+    monkeypatch.setenv("KS_DEBUG_JOIN_SPARSE", sparse)
+    k, scaled, mol = 10, 1, "protein"
+    t_res, t_off = synth.proteome(6000, stream=190)
+    q_res, q_off = synth.queries(5000, t_res, t_off, stream=191)
+    rng = np.random.default_rng(5)
+    extra = [bytes(rng.choice(list(b"ACDEFGHIKLMNPQRSTVWY"), size=n).tolist()) for n in (1600, 4000, 4090, 9000)]
+    seqs = [bytes(q_res[int(q_off[i]):int(q_off[i + 1])]) for i in range(5000)]
+    short = [s[o:o + 40] for s in seqs for o in range(0, len(s) - 39, 20)]   # ~70,000 short sequences: ids well beyond 2^16
+    assert len(short) > 66000
+    seqs = seqs[:100] + extra[:2] + seqs[100:] + short + extra[2:] + [seqs[7]] * 40
+    q_res, q_off = ks.pack(seqs)
+    T = ctx.sketch_batch(t_res, t_off, k, scaled, mol)
+    ix = ctx.index_build(T)
+    plain_Q = ctx.sketch_batch(q_res, q_off, k, scaled, mol)
+    want = ctx.search(ix, plain_Q).to_host()
+    d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
+    Q = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
+    assert Q.posting_bytes == 10
+    for g, w in zip(Q.to_host(), plain_Q.to_host()):
+        assert np.array_equal(g, w)
+    H = ctx.search(ix, Q)
+    assert H.partition_path == 1
+    got = H.to_host()
+    assert len(want[0]) > 10000 and int(want[0].max()) > 70000
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    monkeypatch.setenv("KS_DEBUG_POSTINGS12", "1")
+    Q12 = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
+    assert Q12.posting_bytes == 12
+    for g, w in zip(ctx.search(ix, Q12).to_host(), want):
+        assert np.array_equal(g, w)
+    monkeypatch.delenv("KS_DEBUG_POSTINGS12")
+    # against the oracle: the first 6,000 and the last 3,000 queries (the pairwise oracle over all 73k takes minutes)
+    wt = oracle.sketch_batch(t_res, t_off, k, scaled, mol, n_threads=8)
+    nq = len(q_off) - 1
+    for lo, hi in ((0, 6000), (nq - 3000, nq)):
+        sub_res, sub_off = ks.pack(seqs[lo:hi])
+        wq = oracle.sketch_batch(sub_res, sub_off, k, scaled, mol, n_threads=8)
+        ow = oracle.manysearch(wq[0], wq[1], wt[0], wt[1], wt[2], n_threads=8)
+        sel = (got[0] >= lo) & (got[0] < hi)
+        assert sel.sum() > 100
+        assert np.array_equal(got[0][sel] - lo, ow[0])
+        for g, w in zip(got[1:], ow[1:]):
+            assert np.array_equal(g[sel], w)
+    # a coarser fingerprint overlaps the field the sequence id rides in: the 12-byte form is used
+    monkeypatch.setenv("KS_DEBUG_FP_COARSEN", "8")
+    ix2 = ctx.index_build(T)
+    Q2 = ctx.sketch_queries_device(ix2, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
+    assert Q2.posting_bytes == 12
+    for g, w in zip(ctx.search(ix2, Q2).to_host(), want):
+        assert np.array_equal(g, w)
+    # 10-byte postings made for another index layout are not used: the search partitions from the CSR
+    H2 = ctx.search(ix2, Q)
+    assert H2.partition_path == 3
+    for g, w in zip(H2.to_host(), want):
+        assert np.array_equal(g, w)
+
+
 def test_presorted_postings_fall_back_on_skewed_hashes(ctx):
     """120000 copies of one protein: ~290 distinct hashes land in a few of the 256 fixed-size regions (8 per-XCD
     sub-regions each) and overflow those that receive three or more of them.  The postings are dropped, the sketches are
