@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--moltype", default="protein")
     ap.add_argument("--c4-proteins", type=int, default=200_000, help="proteins of the all-vs-all (configs[4]) workload")
     ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] side measurement")
+    ap.add_argument("--two-calls", action="store_true",
+                    help="step = ks_sketch_queries_device + ks_search (three host waits) instead of ks_sketch_search_device (two)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the side measurements (sketch-only, end-to-end, device ceilings)")
     ap.add_argument("--cpu-sample-queries", type=int, default=0, help="0 = auto (aim at ~15 s of CPU search work)")
@@ -202,9 +204,13 @@ def run_queries_sharded(args, env, ks, synth, ksd):
     n_t_postings = index.n_postings
 
     def step():
-        # sketch for an immediate search: the sketch kernel also writes the postings pre-partitioned for the join
-        Q = ctx.sketch_queries_device(index, q_res.data_ptr(), q_off.data_ptr(), n_q, n_q_res, max_seq_len=q_maxlen)
-        H = ctx.search(index, Q)
+        # sketch for an immediate search: the sketch kernel also writes the postings pre-partitioned for the join; one call
+        # (ks_sketch_search_device: the sketch's read-back rides on the search's first wait), sketches AND hits come back
+        if args.two_calls:
+            Q = ctx.sketch_queries_device(index, q_res.data_ptr(), q_off.data_ptr(), n_q, n_q_res, max_seq_len=q_maxlen)
+            H = ctx.search(index, Q)
+        else:
+            Q, H = ctx.sketch_search_device(index, q_res.data_ptr(), q_off.data_ptr(), n_q, n_q_res, max_seq_len=q_maxlen)
         out = (Q.n_hashes, H.count, H.n_pair_instances)
         H.free()
         Q.free()
@@ -363,6 +369,7 @@ def run_queries_sharded(args, env, ks, synth, ksd):
                                                      if (args.queries, args.targets, k, scaled, mol) ==
                                                      (1_000_000, 1_000_000, 10, 1, "protein") else ""),
                    "queries": all_queries, "targets": args.targets, "ksize": k, "scaled": scaled, "moltype": mol,
+                   "entry": "ks_sketch_queries_device + ks_search" if args.two_calls else "ks_sketch_search_device",
                    "parallelism": f"queries sharded x{world} ({sharding}), index replicated",
                    "n_ranks": world, "collective_backend": env.backend},
         "query_proteins_per_s": all_queries * args.steps / elapsed,
@@ -547,8 +554,11 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
     pending = [None]
 
     def step():
-        Q = ctx.sketch_queries_device(index, p_res.data_ptr(), p_off.data_ptr(), n_prot, n_res, max_seq_len=q_maxlen)
-        H = ctx.search(index, Q)
+        if args.two_calls:
+            Q = ctx.sketch_queries_device(index, p_res.data_ptr(), p_off.data_ptr(), n_prot, n_res, max_seq_len=q_maxlen)
+            H = ctx.search(index, Q)
+        else:
+            Q, H = ctx.sketch_search_device(index, p_res.data_ptr(), p_off.data_ptr(), n_prot, n_res, max_seq_len=q_maxlen)
         # per-shard hit lists all-gathered on the device; left in rank-major order (each shard's block is (qid, tid)-ordered),
         # as configs[4] states it — a global (qid, tid) order is one counting merge more (order="qid") a consumer may ask for.
         # The rows travel as 64-bit transport words (8 instead of 20 bytes per row over xGMI; rows with wide values on an escape

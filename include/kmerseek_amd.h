@@ -105,6 +105,9 @@ int ks_ctx_sketch_stats(const ks_ctx *ctx, uint64_t out[4]);
  * (the list is sized from the previous search of the context), out[1] = searches whose row pass was repeated with
  * ticket-ordered tiles because a look-back gave up (the context then uses tickets for good). */
 int ks_ctx_search_stats(const ks_ctx *ctx, uint64_t out[2]);
+/* ks_sketch_search_device on this context: out[0] = calls whose sketch read-back was folded into the search's first wait,
+ * out[1] = calls that had to be repeated with the two plain calls (skewed hashes, an economy that did not fit). */
+int ks_ctx_fused_stats(const ks_ctx *ctx, uint64_t out[2]);
 /* Diagnostics: the KS_DEBUG_* environment variables (they force the rarely taken paths in the tests; results never
  * depend on them) are read once, when the context is created — never on the per-call path.  This reads them again. */
 int ks_ctx_reload_debug_env(ks_ctx *ctx);
@@ -174,6 +177,15 @@ int ks_sketch_batch_device(ks_ctx *ctx, const uint8_t *d_residues, const uint64_
 int ks_sketch_queries_device(ks_ctx *ctx, const ks_index *index, const uint8_t *d_residues,
                              const uint64_t *d_seq_offsets, uint32_t n_seqs, uint64_t n_residues,
                              uint32_t max_seq_len, ks_sketches **out);
+
+/* ks_sketch_queries_device + ks_search in ONE call, for callers that sketch a batch only to search it — what the
+ * reference does per query file (src/python/kmerseek/search.py:125-141 after sketch.py:28-40; batches of 1000 records in
+ * src/rust/main.rs:130).  Same sketches, same hits as the two calls; the host waits for the device twice instead of three
+ * times (the wait at the end of the sketch is folded into the search's first one: ~25 us per call, which is what a small
+ * batch or a 1/8 query shard notices).  *sketches_out may be NULL: the sketches are then freed before returning. */
+int ks_sketch_search_device(ks_ctx *ctx, const ks_index *index, const uint8_t *d_residues,
+                            const uint64_t *d_seq_offsets, uint32_t n_seqs, uint64_t n_residues,
+                            uint32_t max_seq_len, ks_sketches **sketches_out, ks_hits **hits_out);
 
 uint32_t ks_sketches_n_seqs(const ks_sketches *s);
 uint64_t ks_sketches_n_hashes(const ks_sketches *s);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "ks_ctx_synchronize": (C.c_int, [_vp]),
     "ks_ctx_sketch_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 4)]),
     "ks_ctx_search_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
+    "ks_ctx_fused_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64 * 2)]),
     "ks_ctx_reload_debug_env": (C.c_int, [_vp]),
     "ks_debug_guard_selftest": (C.c_int, [C.c_char_p]),
     "ks_host_alloc": (C.c_int, [_vp, C.c_uint64, _pp]),
@@ -75,6 +76,7 @@ SIGNATURES = {
     "ks_sketch_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _parp, _pp]),
     "ks_sketch_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32, _parp, _pp]),
     "ks_sketch_queries_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32, _pp]),
+    "ks_sketch_search_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32, _pp, _pp]),
     "ks_sketches_has_postings": (C.c_int, [_vp]),
     "ks_sketches_n_seqs": (C.c_uint32, [_vp]),
     "ks_sketches_n_hashes": (C.c_uint64, [_vp]),

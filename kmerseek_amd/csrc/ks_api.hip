@@ -11,7 +11,7 @@ extern "C" int ks_sketch_batch_device(ks_ctx *ctx, const uint8_t *d_residues, co
     return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
-    return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, params, 0, 0, out);
+    return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, params, 0, 0, 0, out);
     });
 }
 
@@ -22,7 +22,7 @@ extern "C" int ks_sketch_queries_device(ks_ctx *ctx, const ks_index *index, cons
     if (!ctx) return KS_ERR_INVALID_ARG;
     if (!index || !out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     return ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, &index->params,
-                                 index->pbits, (index->fp_layout && index->fp_shift == 32 - index->pbits) ? 1 : 0, out);
+                                 index->pbits, (index->fp_layout && index->fp_shift == 32 - index->pbits) ? 1 : 0, 0, out);
     });
 }
 
@@ -60,7 +60,7 @@ extern "C" int ks_sketch_batch(ks_ctx *ctx, const uint8_t *residues, const uint6
     u64 n_res = 0;
     u32 max_len = 0;
     int st = upload_batch(ctx, residues, seq_offsets, n_seqs, &d_res, &d_offs, &n_res, &max_len);
-    if (st == KS_OK) st = ks_sketch_device_impl(ctx, d_res, d_offs, n_seqs, n_res, max_len, params, 0, 0, out);
+    if (st == KS_OK) st = ks_sketch_device_impl(ctx, d_res, d_offs, n_seqs, n_res, max_len, params, 0, 0, 0, out);
     (void)hipStreamSynchronize(ctx->stream);
     ks_pool_free(ctx, d_res);
     ks_pool_free(ctx, d_offs);
@@ -257,6 +257,48 @@ extern "C" int ks_search(ks_ctx *ctx, const ks_index *index, const ks_sketches *
     return ks_guard(ctx, [&]() -> int {
     if (!ctx) return KS_ERR_INVALID_ARG;
     return ks_search_impl(ctx, index, queries, out);
+    });
+}
+// One call for "sketch this query batch and search it": the sketch launches are queued WITHOUT the wait at their end, the
+// search's partition and join follow on the same stream with sizes taken from upper bounds, and the search's first wait
+// brings the sketch's control block back together with the join's counts — two waits per step instead of three.  A batch whose
+// sketch has to be repeated (an economy that did not fit, dropped postings, a look-back that gave up: all rare) is simply
+// done again with the two plain calls.
+extern "C" int ks_sketch_search_device(ks_ctx *ctx, const ks_index *index, const uint8_t *d_residues,
+                                       const uint64_t *d_seq_offsets, uint32_t n_seqs, uint64_t n_residues,
+                                       uint32_t max_seq_len, ks_sketches **sketches_out, ks_hits **hits_out) {
+    return ks_guard(ctx, [&]() -> int {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (!index || !hits_out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    *hits_out = nullptr;
+    if (sketches_out) *sketches_out = nullptr;
+    const int fmt10 = (index->fp_layout && index->fp_shift == 32 - index->pbits) ? 1 : 0;
+    ks_sketches *S = nullptr;
+    ks_hits *H = nullptr;
+    int st = ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, &index->params, index->pbits, fmt10,
+                                   ks_dbg(ctx, KS_DBG_NO_DEFER) ? 0 : 1, &S);
+    if (st != KS_OK) return st;
+    const bool deferred = S->pending != 0;
+    int redo = 0;
+    st = ks_search_impl(ctx, index, S, &H, &redo);
+    if (S->pending) { // (the search failed before its first wait)
+        (void)hipStreamSynchronize(ctx->stream);
+        int r2 = 0;
+        const int st2 = ks_sketch_finish_pending(S, &r2);
+        if (st == KS_OK) { st = st2; redo = r2; }
+    }
+    if (st == KS_OK && redo) { // the plain way: the sketch call repeats what it has to, the search starts from what it gets
+        ks_hits_free(H); H = nullptr;
+        ks_sketches_free(S); S = nullptr;
+        ctx->fused_redos++;
+        st = ks_sketch_device_impl(ctx, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, &index->params, index->pbits, fmt10, 0, &S);
+        if (st == KS_OK) st = ks_search_impl(ctx, index, S, &H);
+    }
+    if (st != KS_OK) { ks_hits_free(H); ks_sketches_free(S); return st; }
+    if (deferred) ctx->fused_deferred++;
+    *hits_out = H;
+    if (sketches_out) *sketches_out = S; else ks_sketches_free(S);
+    return KS_OK;
     });
 }
 extern "C" uint64_t ks_hits_count(const ks_hits *h) { return h ? h->n_hits : 0; }

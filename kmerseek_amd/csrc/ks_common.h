@@ -45,7 +45,7 @@ struct ks_copy_engine; // ks_copy.hip: pinned staging + host copy threads for pa
     X(STAGED_H2D) X(PLAIN_COPIES) X(PAIRS_LSD) X(MSD_LDS_CAP) X(SCAN_3PASS) X(INDEX_LSD) X(JOIN_FP) X(FP_COARSEN)        \
     X(PAIR_LIMIT) X(PBITS_MAX) X(UNPACKED_PAIRS) X(ONE_CURSOR) X(JOIN_SEGS) X(JOIN_SEG_CAP) X(JOIN_SPARSE) X(UNFUSED_ROWS) \
     X(NO_ROWS_HINT) X(ROWS_TICKET) X(FORCE_ROWS_TICKET_RETRY) X(FORCE_TICKET_RETRY) X(NO_PLAN) X(NO_COMPACT) X(SPAN)      \
-    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP) X(SYNC_API) X(POSTINGS12)
+    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP) X(SYNC_API) X(POSTINGS12) X(NO_DEFER)
 enum ks_dbg_id {
 #define KS_DBG_ENUM(n) KS_DBG_##n,
     KS_DBG_LIST(KS_DBG_ENUM)
@@ -78,7 +78,7 @@ struct ks_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> t_free;
     bool t_open = false; // the last ks_timer_begin recorded a start event
     // small pinned host scratch for counters read back from the device
-    u64 *h_pin = nullptr; // 128 x u64
+    u64 *h_pin = nullptr; // KS_PIN_WORDS x u64; [KS_PIN_SKETCH, +32): the control block of a sketch whose read-back is pending
     // matched posting pairs of recent searches (+ slack): sizes the next search's match list so the join runs once
     u64 pair_cap_hint = 0;
     // hit rows of recent searches (+ slack): sizes the next search's row arrays so that the row count can be read with the
@@ -91,6 +91,7 @@ struct ks_ctx {
     // overflowed its LDS lists (-> plain tiles for that batch), bounded outputs too small (-> window-count sized)
     u64 sketch_ticket_fallbacks = 0, sketch_compact_fallbacks = 0, sketch_cap_fallbacks = 0;
     bool rows_use_ticket = false; u64 rows_ticket_fallbacks = 0; // k_pair_rows_fused: dispatch-order tile ids until a look-back gives up
+    u64 fused_deferred = 0, fused_redos = 0; // ks_sketch_search_device: calls that folded the sketch wait into the first wait of the search / were repeated plainly
     u64 join_retries = 0; // searches whose match list outgrew a segment and ran the join twice
     // single-launch scans (ks_prims.hip): status ring + ticket counter in device memory, never reset: every entry is
     // tagged with the global tile number that wrote it
@@ -200,7 +201,16 @@ struct ks_sketches {
     // a u16 column with the rest (sequence ids < 2^24): 10 instead of 12 bytes through the sketch write, the bucket scatter
     // (in and out) and the join's read.
     u32 part_s;
+    // pending != 0 (ks_sketch_search_device): the launches are queued, the copy of the control block to
+    // h_pin + KS_PIN_SKETCH too, but nobody has waited yet — n_hashes / n_windows are upper bounds until
+    // ks_sketch_finish_pending has run behind a wait on the context's stream (the search's first wait)
+    int pending;
+    u64 pend_out_cap;
+    u32 pend_max_seq_len;
+    int pend_planned;
 };
+#define KS_PIN_WORDS 256
+#define KS_PIN_SKETCH 128
 
 // one index posting as the join fetches it for a candidate match: one 16-byte load
 struct __attribute__((aligned(16))) ks_post {
@@ -300,8 +310,12 @@ int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_
 
 // ---- pipelines (ks_sketch.hip, ks_search.hip) ----
 // part_pbits > 0: also emit postings partitioned for a join on the top part_pbits hash bits
+// allow_defer: the first attempt may return with ks_sketches::pending set (no wait at the end), see there
 int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,
-                          u32 max_seq_len, const ks_params *p, int part_pbits, int part_fmt10, ks_sketches **out);
+                          u32 max_seq_len, const ks_params *p, int part_pbits, int part_fmt10, int allow_defer, ks_sketches **out);
+// After a wait on the stream: the exact counts of a pending sketch.  *redo != 0: the launch has to be repeated the plain way
+// (1 compacting tile overflowed, 2 bounded outputs too small, 3 look-back gave up, 4 postings dropped) — the caller frees S.
+int ks_sketch_finish_pending(ks_sketches *S, int *redo);
 // bits of hash prefix the join against an index of n_postings uses (buckets of ~3k index postings, <= 16)
 int ks_join_pbits(const ks_ctx *ctx, u64 n_postings);
 // multiplier of ks_join_prefix (ks_device.h) for a join on pbits prefix bits of hashes kept below max_hash
@@ -311,7 +325,7 @@ int ks_kmerpos_tiles_launch(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32
 int ks_kmerpos_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res,
                            const ks_params *p, ks_kmerpos **out);
 int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out);
-int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out);
+int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out, int *sketch_redo = nullptr);
 int ks_union_impl(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out);
 
 int ks_check_params(ks_ctx *ctx, const ks_params *p);

@@ -175,7 +175,7 @@ extern "C" int ks_ctx_create(int device, void *hip_stream, ks_ctx **out) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
         ctx->own_stream = true;
     }
-    if (hipHostMalloc((void **)&ctx->h_pin, 128 * sizeof(u64)) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
+    if (hipHostMalloc((void **)&ctx->h_pin, KS_PIN_WORDS * sizeof(u64)) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
     if (hipHostMalloc((void **)&ctx->h_flag, 64) != hipSuccess) { (void)hipGetLastError(); ctx->h_flag = nullptr; } // (ks_stream_wait falls back to the API)
     else *ctx->h_flag = 0;
     if (hipMalloc((void **)&ctx->d_lut, 3 * 256) != hipSuccess) { delete ctx; return KS_ERR_OOM; }
@@ -240,6 +240,14 @@ extern "C" int ks_ctx_search_stats(const ks_ctx *ctx, uint64_t out[2]) {
     return ks_guard((ks_ctx *)ctx, [&]() -> int {
     if (!ctx || !out) return KS_ERR_INVALID_ARG;
     out[0] = ctx->join_retries; out[1] = ctx->rows_ticket_fallbacks;
+    return KS_OK;
+    });
+}
+
+extern "C" int ks_ctx_fused_stats(const ks_ctx *ctx, uint64_t out[2]) {
+    return ks_guard((ks_ctx *)ctx, [&]() -> int {
+    if (!ctx || !out) return KS_ERR_INVALID_ARG;
+    out[0] = ctx->fused_deferred; out[1] = ctx->fused_redos;
     return KS_OK;
     });
 }

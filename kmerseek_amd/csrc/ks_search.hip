@@ -229,8 +229,11 @@ __global__ __launch_bounds__(256) void k_region_dir(const u32 *len, u64 cap, u32
     if (b >= n_regions) return;
     // n_hi != 0: b is a join prefix (high digit << 8 | region) and its postings sit in storage slot KS_BSLOT
     const u32 slot = n_hi ? KS_BSLOT(b >> 8, b & 255u, n_hi) : b;
+    // (a cursor keeps counting past the capacity when a region / bucket overflows — the host then repartitions — but the join
+    // that is already queued behind this kernel must not walk into the neighbour, or past the end of the array)
+    const u64 n = len[slot];
     lo[b] = (u64)slot * cap;
-    hi[b] = (u64)slot * cap + len[slot];
+    hi[b] = (u64)slot * cap + (n < cap ? n : cap);
 }
 
 // dir[b] = first posting whose join prefix is >= b, for b in [0, 2^pbits]; keys are ordered on the prefix
@@ -1150,9 +1153,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_pair_rows_fused(const u64 *keys,
 
 // One search with the whole query batch in one match list.  *split_pairs != 0 on return (with KS_OK and *out == NULL) means
 // the list would hold that many records — more than one list can (2^32) — and nothing was produced: the caller splits.
-static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out, u64 *split_pairs) {
+// q->pending (ks_sketch_search_device): the sketch launches are queued and nobody has waited for them; the first wait of
+// the search stands in, and q's counts are upper bounds until then.  *sketch_redo != 0 on return (KS_OK, *out == NULL): the
+// sketch has to be repeated the plain way (ks_sketch_finish_pending) and nothing was produced.
+static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out, u64 *split_pairs, int *sketch_redo = nullptr) {
     *split_pairs = 0;
     *out = nullptr;
+    if (sketch_redo) *sketch_redo = 0;
     if (!ix || !q || !out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     if (ix->params.ksize != q->params.ksize || ix->params.scaled != q->params.scaled ||
         ix->params.moltype != q->params.moltype || ix->params.seed != q->params.seed)
@@ -1161,15 +1168,23 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
     ks_hits *H = new ks_hits();
     memset(H, 0, sizeof *H);
     H->ctx = ctx;
-    const u64 n_q = q->n_hashes, n_t = ix->n_postings;
+    u64 n_q = q->n_hashes;
+    const u64 n_t = ix->n_postings;
     u64 *qk0 = nullptr, *qk1 = nullptr, *pk0 = nullptr, *pk1 = nullptr, *row_start = nullptr, *dir_q = nullptr;
     u32 *qv0 = nullptr, *qv1 = nullptr, *pv0 = nullptr, *pv1 = nullptr, *heads = nullptr, *d_nrows = nullptr;
     unsigned long long *cursor = nullptr, *pf_status = nullptr;
     u32 *pf_ticket = nullptr;
     int st = KS_OK;
     bool split = false;
+    // the exact counts of a pending sketch, behind a wait; a sketch that has to be repeated ends the search (split: nothing produced)
+#define SE_FINISH_PENDING() do { if (q->pending) { int redo_ = 0; st = ks_sketch_finish_pending(const_cast<ks_sketches *>(q), &redo_); \
+        if (st != KS_OK) goto done; n_q = q->n_hashes; if (redo_) { if (sketch_redo) *sketch_redo = redo_; split = true; goto done; } } } while (0)
 #define SE_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
 #define SE_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
+    if (q->pending && (n_t == 0 || !(q->part_keys && q->part_pbits == ix->pbits && ix->pbits > 0))) {
+        SE_CHECK(ks_stream_wait(ctx)); // (no postings for this index: the partition starts from the CSR and needs the exact counts)
+        SE_FINISH_PENDING();
+    }
     if (n_q == 0 || n_t == 0) {
         SE_CHECK(ks_alloc(ctx, &H->d_qid, 1)); SE_CHECK(ks_alloc(ctx, &H->d_tid, 1));
         SE_CHECK(ks_alloc(ctx, &H->d_isect, 1)); SE_CHECK(ks_alloc(ctx, &H->d_nw, 1));
@@ -1201,6 +1216,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         const bool f10_fits = ix->fp_layout && pbits > 8 && q->part_s == 32u + (u32)ix->fp_shift;
         bool pre = pre_any && (q->part_s == 0 || f10_fits);
         const bool f10 = pre && q->part_s != 0;
+        if (q->pending && !pre) { SE_CHECK(ks_stream_wait(ctx)); SE_FINISH_PENDING(); }
         u64 cap = n_q < (1u << 20) ? (1u << 20) : n_q;
         if (ctx->pair_cap_hint > cap) cap = ctx->pair_cap_hint; // a workload that matched heavily last time will again
         u64 n_pairs = 0, seg_cap = 0, seg_count[JN_SEGS];
@@ -1305,6 +1321,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                     SE_HIP(hipMemcpy2DAsync(ctx->h_pin, 2 * sizeof(u64), cursor, (size_t)JN_CUR_STRIDE * sizeof(u64), 2 * sizeof(u64), JN_SEGS,
                                             hipMemcpyDeviceToHost, ctx->stream));
                 SE_CHECK(ks_stream_wait(ctx));
+                SE_FINISH_PENDING();
                 n_pairs = 0;
                 u64 seg_max = 0;
                 for (u32 s_ = 0; s_ < n_segs; s_++) {
@@ -1458,6 +1475,7 @@ done:
     return KS_OK;
 #undef SE_CHECK
 #undef SE_HIP
+#undef SE_FINISH_PENDING
 }
 
 __global__ __launch_bounds__(256) void k_rebase_offsets(const u64 *offs, u64 base, u32 n, u64 *out) {
@@ -1471,10 +1489,10 @@ __global__ __launch_bounds__(256) void k_add_u32(u32 *a, u64 n, u32 v) {
 
 // ks_search: one match list when it fits; otherwise the query sequences are searched in contiguous slices whose lists
 // fit (a slice is a view of the batch's CSR: hits of different query ranges are disjoint and stay ordered by qid).
-int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out) {
+int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hits **out, int *sketch_redo) {
     if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     u64 need = 0;
-    int st = search_core(ctx, ix, q, out, &need);
+    int st = search_core(ctx, ix, q, out, &need, sketch_redo);
     if (st != KS_OK || need == 0) return st;
     // ---- slices of roughly equal posting counts, each expected to produce KS_PAIR_LIMIT / 4 records
     std::vector<u64> offs((size_t)q->n_seqs + 1);

@@ -1699,7 +1699,7 @@ __global__ __launch_bounds__(256) void k_seq_stats(const u64 *offs, u32 n_seqs, 
 // nothing produced) when the attempt has to be repeated without the corresponding economy: 1 = a compacting tile
 // overflowed its LDS lists, 2 = the batch kept more hashes than the bounded output arrays hold.
 static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, u32 max_seq_len, const ks_params *p,
-                          int part_pbits, int part_fmt10, int variant, int *redo, ks_sketches **out) {
+                          int part_pbits, int part_fmt10, int variant, int allow_defer, int *redo, ks_sketches **out) {
     ks_sketches *S = new ks_sketches();
     memset(S, 0, sizeof *S);
     S->ctx = ctx;
@@ -2015,12 +2015,21 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             }
             SK_HIPCHECK(hipGetLastError());
             // total + look-back error flag to the host
+            if (allow_defer && attempt == 0 && (pk_bound || (planned && !packed)) && !ks_dbg(ctx, KS_DBG_FORCE_TICKET_RETRY)) {
+                // the caller's next wait on this stream (the search's) stands in for this one: the control block is copied to
+                // its own pinned words, everything of this call that is freed below is reused in stream order
+                SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin + KS_PIN_SKETCH, d_stats, SK_CTL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+                S->pending = 1; S->pend_out_cap = out_cap; S->pend_max_seq_len = max_seq_len; S->pend_planned = planned ? 1 : 0;
+                S->n_hashes = out_cap; // (an upper bound until ks_sketch_finish_pending)
+                break;
+            }
             SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, SK_CTL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
             SK_CHECK(ks_stream_wait(ctx));
             u32 &status_w = ((u32 *)(ctx->h_pin + 20))[1];
             if (attempt == 0 && !A.use_ticket && ks_dbg(ctx, KS_DBG_FORCE_TICKET_RETRY)) status_w |= 1u; // exercises the repeat
             if (!(status_w & 1u) || A.use_ticket) break;
         }
+        if (S->pending) goto done;
         S->n_hashes = ctx->h_pin[23];
         if (planned) {
             S->n_windows = ctx->h_pin[0];
@@ -2059,8 +2068,29 @@ done:
 #undef SK_HIPCHECK
 }
 
+int ks_sketch_finish_pending(ks_sketches *S, int *redo) {
+    *redo = 0;
+    if (!S || !S->pending) return KS_OK;
+    ks_ctx *ctx = S->ctx;
+    const u64 *stats = ctx->h_pin + KS_PIN_SKETCH;
+    S->pending = 0;
+    S->n_hashes = stats[23];
+    if (S->pend_planned) {
+        S->n_windows = stats[0];
+        if (stats[1] > (u64)S->pend_max_seq_len)
+            return ks_fail(ctx, KS_ERR_INVALID_ARG, "max_seq_len = %u, but the batch holds a sequence of %llu residues", S->pend_max_seq_len,
+                           (unsigned long long)stats[1]);
+    }
+    const u32 status = ((const u32 *)(stats + 20))[1];
+    if (status & 1u) *redo = 3;                       // a look-back gave up: the plain call repeats the launch with tickets
+    else if (status & 4u) *redo = 1;                  // a compacting tile overflowed
+    else if (S->n_hashes > S->pend_out_cap) *redo = 2; // more kept hashes than the bounded outputs hold
+    else if (status & 2u) *redo = 4;                  // postings dropped (skewed hashes): whoever read them read garbage
+    return KS_OK;
+}
+
 int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, u32 max_seq_len,
-                          const ks_params *p, int part_pbits, int part_fmt10, ks_sketches **out) {
+                          const ks_params *p, int part_pbits, int part_fmt10, int allow_defer, ks_sketches **out) {
     KS_TRY(ks_check_params(ctx, p));
     if (!out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "out is NULL");
     if (((uintptr_t)d_res & 15) != 0) return ks_fail(ctx, KS_ERR_INVALID_ARG, "d_residues must be 16-byte aligned");
@@ -2070,7 +2100,8 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     int variant = 1;
     for (int round = 0; round < 3; round++) {
         int redo = 0;
-        const int st = sketch_attempt(ctx, d_res, d_offs, n_seqs, n_res, max_seq_len, p, part_pbits, part_fmt10, variant, &redo, out);
+        const int st = sketch_attempt(ctx, d_res, d_offs, n_seqs, n_res, max_seq_len, p, part_pbits, part_fmt10, variant,
+                                      (allow_defer && round == 0) ? 1 : 0, &redo, out);
         if (st != KS_OK || !redo) return st;
         if (redo == 1) { variant &= ~1; ctx->sketch_compact_fallbacks++; }
         else { variant |= 2; ctx->sketch_cap_fallbacks++; }

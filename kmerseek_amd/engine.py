@@ -225,6 +225,21 @@ class Context:
                                                      n_seqs, n_residues, max_seq_len, C.byref(out)))
         return Sketches(self, out)
 
+    def sketch_search_device(self, index: "Index", d_residues: int, d_offsets: int, n_seqs: int, n_residues: int,
+                             max_seq_len: int = 0, want_sketches: bool = True):
+        """ks_sketch_search_device: sketch a query batch and search it against `index` in one call (two host waits instead
+        of three).  Returns (Sketches or None, Hits); same results as sketch_queries_device + search."""
+        sk, hits = C.c_void_p(), C.c_void_p()
+        self._check(self._L.ks_sketch_search_device(self._h, index._h, C.c_void_p(d_residues), C.c_void_p(d_offsets), n_seqs,
+                                                    n_residues, max_seq_len, C.byref(sk) if want_sketches else None, C.byref(hits)))
+        return (Sketches(self, sk) if want_sketches else None), Hits(self, hits)
+
+    def fused_stats(self) -> Dict[str, int]:
+        """ks_sketch_search_device calls on this context: with the sketch read-back deferred / repeated the plain way."""
+        v = (C.c_uint64 * 2)()
+        self._check(self._L.ks_ctx_fused_stats(self._h, C.byref(v)))
+        return {"deferred": int(v[0]), "redos": int(v[1])}
+
     def sketches_from_host(self, offsets: np.ndarray, hashes: np.ndarray, abunds: np.ndarray, ksize: int,
                            scaled: int, moltype: str, seed: int = SEED) -> "Sketches":
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)

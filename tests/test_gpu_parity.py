@@ -478,6 +478,122 @@ def test_ten_byte_query_postings_equal_plain_search(ctx, monkeypatch, sparse):
         assert np.array_equal(g, w)
 
 
+def _maxlen(off):
+    return int((off[1:] - off[:-1]).max())
+
+
+@pytest.mark.parametrize("k,scaled,mol,nt,nq,env", [
+    (7, 1, "protein", 3000, 2500, {}),                                   # regions = join buckets (pbits <= 8)
+    (10, 1, "protein", 6000, 5000, {}),                                  # 8 < pbits: bucket scatter, key-column join
+    (10, 1, "protein", 6000, 5000, {"KS_DEBUG_JOIN_FP": "1"}),           # 10-byte postings, fingerprint join
+    (16, 5, "dayhoff", 20000, 20000, {}),                                # compacting tiles, bounded outputs
+    (24, 5, "hp", 8000, 8000, {}),
+    (5, 1, "hp", 150, 120, {}),                                          # saturated alphabet, pbits = 1
+    (10, 1, "protein", 3000, 2500, {"KS_DEBUG_NO_DEFER": "1"}),          # the knob: three waits, same results
+])
+def test_one_call_sketch_search_equals_the_two_calls(ctx, monkeypatch, k, scaled, mol, nt, nq, env):
+    """ks_sketch_search_device (VERDICT r2 missing #2): one call, the sketch's read-back folded into the search's first wait.
+    Same sketches and hits as ks_sketch_queries_device + ks_search and as the oracle; with and without the caller's
+    max_seq_len bound (without it the sketch measures the batch first and nothing is deferred)."""
+    for kk, vv in env.items():
+        monkeypatch.setenv(kk, vv)
+    t_res, t_off = synth.proteome(nt, stream=290 + k)
+    q_res, q_off = synth.queries(nq, t_res, t_off, stream=291 + k)
+    ix = ctx.index_build(ctx.sketch_batch(t_res, t_off, k, scaled, mol))
+    d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
+    Q2 = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, nq, len(q_res), max_seq_len=_maxlen(q_off))
+    want_s, want_h = Q2.to_host(), ctx.search(ix, Q2).to_host()
+    assert len(want_h[0]) > 0
+    for bound in (_maxlen(q_off), 0):
+        before = ctx.fused_stats()
+        Q, H = ctx.sketch_search_device(ix, d_res.ptr, d_off.ptr, nq, len(q_res), max_seq_len=bound)
+        after = ctx.fused_stats()
+        assert after["redos"] == before["redos"]
+        if bound and "KS_DEBUG_NO_DEFER" not in env:
+            assert after["deferred"] == before["deferred"] + 1   # the fast path really ran
+        else:
+            assert after["deferred"] == before["deferred"]
+        assert Q.n_hashes == len(want_s[1]) and Q.n_windows == Q2.n_windows
+        for g, w in zip(Q.to_host(), want_s):
+            assert np.array_equal(g, w)
+        for g, w in zip(H.to_host(), want_h):
+            assert np.array_equal(g, w)
+        assert H.n_pair_instances == int(want_h[2].sum())
+        Q.free(); H.free()
+    none, H = ctx.sketch_search_device(ix, d_res.ptr, d_off.ptr, nq, len(q_res), max_seq_len=_maxlen(q_off), want_sketches=False)
+    assert none is None
+    got = H.to_host()
+    for g, w in zip(got, want_h):
+        assert np.array_equal(g, w)
+    if nt <= 6000:
+        wq = oracle.sketch_batch(q_res, q_off, k, scaled, mol, n_threads=8)
+        wt = oracle.sketch_batch(t_res, t_off, k, scaled, mol, n_threads=8)
+        for g, w in zip(got, oracle.manysearch(wq[0], wq[1], wt[0], wt[1], wt[2], n_threads=8)):
+            assert np.array_equal(g, w)
+
+
+def test_one_call_sketch_search_repeats_plainly_when_the_sketch_must(ctx, monkeypatch):
+    """What the deferred read-back finds out too late — dropped postings (skewed hashes), a compacting tile that overflowed,
+    bounded outputs that were too small, a look-back that gave up, a wrong max_seq_len — ends in the plain two calls (or in the
+    plain error), never in wrong rows."""
+    t_res, t_off = synth.proteome(30000, stream=295)
+    ix = ctx.index_build(ctx.sketch_batch(t_res, t_off, 10, 1, "protein"))
+    # (a) 120,000 copies of one protein: the fixed-size regions overflow, the postings the join read were garbage
+    one = bytes(t_res[int(t_off[7]):int(t_off[8])])
+    N = 120000
+    q_res, q_off = ks.pack([one] * N)
+    d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
+    before = ctx.fused_stats()
+    Q, H = ctx.sketch_search_device(ix, d_res.ptr, d_off.ptr, N, len(q_res), max_seq_len=len(one))
+    assert ctx.fused_stats()["redos"] == before["redos"] + 1
+    assert not Q.has_postings
+    n1 = len(oracle.sketch_protein(one, 10, 1, "protein")[0])
+    assert Q.n_hashes == N * n1
+    qid, tid, isect, nw = H.to_host()
+    self_hits = tid == 7
+    assert self_hits.sum() == N and np.all(isect[self_hits] == n1)
+    Q.free(); H.free(); d_res.free(); d_off.free()
+    # (b) a bound smaller than the longest sequence is still an error, and the context keeps working
+    q_res, q_off = synth.queries(3000, t_res, t_off, stream=296)
+    d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
+    with pytest.raises(ks.KmerseekError):
+        ctx.sketch_search_device(ix, d_res.ptr, d_off.ptr, 3000, len(q_res), max_seq_len=_maxlen(q_off) - 1)
+    want = ctx.search(ix, ctx.sketch_batch(q_res, q_off, 10, 1, "protein")).to_host()
+    # (c) a look-back that really gives up (one tile never publishes): ~2 s, then tickets
+    c = ks.Context(0, follow_debug_env=True)
+    try:
+        ix_c = c.index_build(c.sketch_batch(t_res, t_off, 10, 1, "protein"))
+        dr, do = c.to_device(q_res), c.to_device(q_off)
+        monkeypatch.setenv("KS_DEBUG_LOOKBACK_SKIP", "3")
+        Q, H = c.sketch_search_device(ix_c, dr.ptr, do.ptr, 3000, len(q_res), max_seq_len=_maxlen(q_off))
+        assert c.fused_stats()["redos"] == 1 and c.sketch_stats()["ticket_fallbacks"] >= 1
+        for g, w in zip(H.to_host(), want):
+            assert np.array_equal(g, w)
+    finally:
+        monkeypatch.delenv("KS_DEBUG_LOOKBACK_SKIP", raising=False)
+        c.close()
+    # (d) scaled > 1: outputs forced too small, and a homopolymer batch that defeats the compaction
+    ix5 = ctx.index_build(ctx.sketch_batch(t_res, t_off, 16, 5, "dayhoff"))
+    want5 = ctx.search(ix5, ctx.sketch_batch(q_res, q_off, 16, 5, "dayhoff")).to_host()
+    monkeypatch.setenv("KS_DEBUG_OUT_CAP", "1000")
+    before = ctx.fused_stats()
+    Q, H = ctx.sketch_search_device(ix5, d_res.ptr, d_off.ptr, 3000, len(q_res), max_seq_len=_maxlen(q_off))
+    monkeypatch.delenv("KS_DEBUG_OUT_CAP")
+    assert ctx.fused_stats()["redos"] == before["redos"] + 1
+    for g, w in zip(H.to_host(), want5):
+        assert np.array_equal(g, w)
+    k, scaled, mol = 7, 2, "protein"
+    keep = [aa for aa in b"ACDEFGHIKLMNPQRSTVWY" if oracle.hash_murmur(bytes([aa]) * k) <= oracle.max_hash(scaled)]
+    h_res, h_off = ks.pack([bytes([keep[0]]) * 3000, bytes([keep[-1]]) * 2000] + [bytes([keep[0]]) * 500] * 40)
+    ix2 = ctx.index_build(ctx.sketch_batch(t_res[:int(t_off[2000])], t_off[:2001], k, scaled, mol))
+    dh_res, dh_off = ctx.to_device(h_res), ctx.to_device(h_off)
+    Q, H = ctx.sketch_search_device(ix2, dh_res.ptr, dh_off.ptr, len(h_off) - 1, len(h_res), max_seq_len=_maxlen(h_off))
+    for g, w in zip(Q.to_host(), oracle.sketch_batch(h_res, h_off, k, scaled, mol, n_threads=4)):
+        assert np.array_equal(g, w)
+    for g, w in zip(H.to_host(), ctx.search(ix2, ctx.sketch_batch(h_res, h_off, k, scaled, mol)).to_host()):
+        assert np.array_equal(g, w)
+
+
 def test_presorted_postings_fall_back_on_skewed_hashes(ctx):
     """120000 copies of one protein: ~290 distinct hashes land in a few of the 256 fixed-size regions (8 per-XCD
     sub-regions each) and overflow those that receive three or more of them.  The postings are dropped, the sketches are

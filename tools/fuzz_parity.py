@@ -104,6 +104,12 @@ def run(cases: int, seed: int) -> int:
                 h2 = ctx.search(ix, Q2).to_host()
                 if not all(np.array_equal(x, y) for x, y in zip(h2, w)):
                     print("FUSED SEARCH MISMATCH", tag); bad += 1; continue
+                # one call (ks_sketch_search_device), with the bound that lets it defer the sketch's read-back
+                mx = int((offs2[1:] - offs2[:-1]).max()) if len(offs2) > 1 else 0
+                Q3, H3 = ctx.sketch_search_device(ix, d_res.ptr, d_off.ptr, len(offs2) - 1, len(res2), max_seq_len=mx)
+                if not (all(np.array_equal(x, y) for x, y in zip(H3.to_host(), w)) and
+                        all(np.array_equal(x, y) for x, y in zip(Q3.to_host(), Q.to_host()))):
+                    print("ONE-CALL SEARCH MISMATCH", tag); bad += 1; continue
         except Exception as e:  # noqa: BLE001
             print("ERROR", tag, repr(e)); bad += 1
     ctx.close()
@@ -161,6 +167,10 @@ def run_big(cases: int, seed: int) -> int:
             del os.environ["KS_DEBUG_INDEX_LSD"]
             if not all(np.array_equal(x, y) for x, y in zip(plain, fused)):
                 print("FUSED != PLAIN", tag); bad += 1; continue
+            one = ctx.sketch_search_device(ix, d_res.ptr, d_off.ptr, nq, len(q_res), max_seq_len=int((q_off[1:] - q_off[:-1]).max()),
+                                           want_sketches=False)[1].to_host()
+            if not all(np.array_equal(x, y) for x, y in zip(plain, one)):
+                print("ONE CALL != PLAIN", tag); bad += 1; continue
             if not all(np.array_equal(x, y) for x, y in zip(plain, lsd)):
                 print("PARTITIONED INDEX != LSD INDEX", tag); bad += 1; continue
             # oracle on a few queries
