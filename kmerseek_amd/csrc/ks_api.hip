@@ -147,7 +147,8 @@ extern "C" void ks_sketches_free(ks_sketches *s) {
     ks_pool_free(s->ctx, s->d_abunds);
     ks_pool_free(s->ctx, s->part_keys);
     ks_pool_free(s->ctx, s->part_vals);
-    ks_pool_free(s->ctx, s->part_len);
+    if (s->ctl_block) ks_pool_free(s->ctx, s->ctl_block); // (part_len lies inside it)
+    else ks_pool_free(s->ctx, s->part_len);
     delete s;
 }
 
@@ -282,9 +283,10 @@ extern "C" int ks_sketch_search_device(ks_ctx *ctx, const ks_index *index, const
     int redo = 0;
     st = ks_search_impl(ctx, index, S, &H, &redo);
     if (S->pending) { // (the search failed before its first wait)
-        (void)hipStreamSynchronize(ctx->stream);
+        const ks_fetch_seg f = ks_sketch_pending_seg(S);
         int r2 = 0;
-        const int st2 = ks_sketch_finish_pending(S, &r2);
+        int st2 = ks_stream_wait_fetch(ctx, &f, 1);
+        if (st2 == KS_OK) st2 = ks_sketch_finish_pending(S, &r2);
         if (st == KS_OK) { st = st2; redo = r2; }
     }
     if (st == KS_OK && redo) { // the plain way: the sketch call repeats what it has to, the search starts from what it gets
@@ -511,7 +513,7 @@ extern "C" void ks_hits_free(ks_hits *h) {
     if (!h) return;
     ks_pool_free(h->ctx, h->d_qid);
     ks_pool_free(h->ctx, h->d_tid);
-    ks_pool_free(h->ctx, h->d_isect);
-    ks_pool_free(h->ctx, h->d_nw);
+    if (h->d_block) ks_pool_free(h->ctx, h->d_block); // (d_isect and d_nw lie inside it)
+    else { ks_pool_free(h->ctx, h->d_isect); ks_pool_free(h->ctx, h->d_nw); }
     delete h;
 }

@@ -109,6 +109,16 @@ struct ks_ctx {
 // that a one-thread kernel at the end of the queue stamps: the wake-up of a blocking synchronisation costs 10 - 25 us of idle
 // queue on this runtime, and a sketch + search step waits three times.  KS_DEBUG_SYNC_API = the runtime's call instead.
 int ks_stream_wait(ks_ctx *ctx);
+// ... and the same with the words the host wants to read afterwards: the stamping kernel writes them to pinned memory itself
+// (instead of one device -> host copy dispatch per block before it).  dst must lie in pinned host memory (ctx->h_pin).
+#define KS_FETCH_MAX 4
+struct ks_fetch_seg {
+    const void *src; // device
+    u32 *dst;        // pinned host
+    u32 rows, row_words, src_stride; // 32-bit words
+};
+static inline ks_fetch_seg ks_fetch_words(const void *src, void *dst, u32 n_words32) { return ks_fetch_seg{src, (u32 *)dst, 1u, n_words32, n_words32}; }
+int ks_stream_wait_fetch(ks_ctx *ctx, const ks_fetch_seg *segs, int n);
 
 // returns nullptr and sets ctx->err on failure
 void *ks_pool_alloc(ks_ctx *ctx, size_t bytes);
@@ -204,7 +214,11 @@ struct ks_sketches {
     // pending != 0 (ks_sketch_search_device): the launches are queued, the copy of the control block to
     // h_pin + KS_PIN_SKETCH too, but nobody has waited yet — n_hashes / n_windows are upper bounds until
     // ks_sketch_finish_pending has run behind a wait on the context's stream (the search's first wait)
+    // the sketch call's control block (device): statistics | posting cursors (part_len points INTO it) | tile status words —
+    // one allocation, one memset per call; freed with the object
+    u64 *ctl_block;
     int pending;
+    u64 *pend_stats; // the statistics words of ctl_block, read back by the caller's next wait
     u64 pend_out_cap;
     u32 pend_max_seq_len;
     int pend_planned;
@@ -253,6 +267,8 @@ struct ks_hits {
     int partition_path; // how the query postings reached their join buckets (see ks_hits_partition_path)
     u32 *d_qid, *d_tid, *d_isect;
     u64 *d_nw;
+    // != NULL: d_nw and d_isect point INTO this block (with the row pass's status words: one allocation, one memset)
+    u64 *d_block;
 };
 
 struct ks_kmerpos {
@@ -316,6 +332,10 @@ int ks_sketch_device_impl(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
 // After a wait on the stream: the exact counts of a pending sketch.  *redo != 0: the launch has to be repeated the plain way
 // (1 compacting tile overflowed, 2 bounded outputs too small, 3 look-back gave up, 4 postings dropped) — the caller frees S.
 int ks_sketch_finish_pending(ks_sketches *S, int *redo);
+// the fetch segment (ks_stream_wait_fetch) that brings a pending sketch's control block to h_pin + KS_PIN_SKETCH
+ks_fetch_seg ks_sketch_pending_seg(const ks_sketches *S);
+// the fetch segment of the one-launch scans' give-up flag (see ks_scan_status_check); false: nothing to fetch
+bool ks_scan_status_seg(ks_ctx *ctx, ks_fetch_seg *out);
 // bits of hash prefix the join against an index of n_postings uses (buckets of ~3k index postings, <= 16)
 int ks_join_pbits(const ks_ctx *ctx, u64 n_postings);
 // multiplier of ks_join_prefix (ks_device.h) for a join on pbits prefix bits of hashes kept below max_hash

@@ -291,6 +291,52 @@ extern "C" int ks_dev_download(ks_ctx *ctx, void *dst, const void *src, uint64_t
 __global__ void k_host_stamp(unsigned long long *flag, unsigned long long seq) {
     __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// The words the host is waiting for, written to its pinned block by the SAME one-workgroup kernel that stamps: a device ->
+// host copy of a few words is a dispatch of its own on this runtime (~4.5 us of queue each), and a step reads back three to
+// five such blocks.  Up to KS_FETCH_MAX segments; a segment is `rows` rows of `row_words` 32-bit words, `src_stride` words apart
+// in device memory, packed densely at dst.
+struct ks_fetch_args { ks_fetch_seg seg[KS_FETCH_MAX]; int n; };
+__global__ __launch_bounds__(256) void k_host_report(ks_fetch_args F, unsigned long long *flag, unsigned long long seq) {
+    for (int s = 0; s < F.n; s++) {
+        const ks_fetch_seg g = F.seg[s];
+        const u32 total = g.rows * g.row_words;
+        for (u32 i = threadIdx.x; i < total; i += blockDim.x) {
+            const u32 r = i / g.row_words, c = i - r * g.row_words;
+            const u32 v = __hip_atomic_load((const u32 *)g.src + (size_t)r * g.src_stride + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static int stream_wait_poll(ks_ctx *ctx, unsigned long long seq);
+
+int ks_stream_wait_fetch(ks_ctx *ctx, const ks_fetch_seg *segs, int n) {
+    if (n > KS_FETCH_MAX) return ks_fail(ctx, KS_ERR_INVALID_ARG, "too many fetch segments");
+    if (!ctx->h_flag || ks_dbg(ctx, KS_DBG_SYNC_API)) {
+        for (int i = 0; i < n; i++) {
+            const ks_fetch_seg &g = segs[i];
+            if (g.rows == 1 || g.src_stride == g.row_words)
+                KS_HIP(ctx, hipMemcpyAsync(g.dst, g.src, (size_t)g.rows * g.row_words * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+            else
+                KS_HIP(ctx, hipMemcpy2DAsync(g.dst, (size_t)g.row_words * sizeof(u32), g.src, (size_t)g.src_stride * sizeof(u32),
+                                            (size_t)g.row_words * sizeof(u32), g.rows, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return KS_OK;
+    }
+    ks_fetch_args F;
+    memset(&F, 0, sizeof F);
+    for (int i = 0; i < n; i++) F.seg[i] = segs[i];
+    F.n = n;
+    const unsigned long long seq = ++ctx->wait_seq;
+    hipLaunchKernelGGL(k_host_report, dim3(1), dim3(256), 0, ctx->stream, F, ctx->h_flag, seq);
+    if (hipGetLastError() != hipSuccess) return ks_fail(ctx, KS_ERR_HIP, "k_host_report launch failed");
+    return stream_wait_poll(ctx, seq);
+}
+
 int ks_stream_wait(ks_ctx *ctx) {
     if (!ctx->h_flag || ks_dbg(ctx, KS_DBG_SYNC_API)) {
         KS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -299,6 +345,10 @@ int ks_stream_wait(ks_ctx *ctx) {
     const unsigned long long seq = ++ctx->wait_seq;
     hipLaunchKernelGGL(k_host_stamp, dim3(1), dim3(1), 0, ctx->stream, ctx->h_flag, seq);
     if (hipGetLastError() != hipSuccess) { KS_HIP(ctx, hipStreamSynchronize(ctx->stream)); return KS_OK; }
+    return stream_wait_poll(ctx, seq);
+}
+
+static int stream_wait_poll(ks_ctx *ctx, unsigned long long seq) {
     // (the stamp arrives behind every copy and kernel queued before it; a stream that has failed never stamps: the
     // runtime is asked now and then, and after a while it is simply left to the blocking call)
     for (unsigned spins = 1;; spins++) {

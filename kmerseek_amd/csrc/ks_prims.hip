@@ -243,6 +243,11 @@ int ks_scan_status_fetch(ks_ctx *ctx) {
     KS_HIP(ctx, hipMemcpyAsync(ctx->h_pin + 40, ctx->scan_ticket + 1, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
     return KS_OK;
 }
+bool ks_scan_status_seg(ks_ctx *ctx, ks_fetch_seg *out) {
+    if (!ctx->scan_ticket) return false;
+    *out = ks_fetch_words(ctx->scan_ticket + 1, ctx->h_pin + 40, 1);
+    return true;
+}
 int ks_scan_status_check(ks_ctx *ctx) {
     if (!ctx->scan_ticket || *(u32 *)(ctx->h_pin + 40) == 0) return KS_OK;
     *(u32 *)(ctx->h_pin + 40) = 0;

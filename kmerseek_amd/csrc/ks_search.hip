@@ -1182,7 +1182,8 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
 #define SE_CHECK(x) do { st = (x); if (st != KS_OK) goto done; } while (0)
 #define SE_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
     if (q->pending && (n_t == 0 || !(q->part_keys && q->part_pbits == ix->pbits && ix->pbits > 0))) {
-        SE_CHECK(ks_stream_wait(ctx)); // (no postings for this index: the partition starts from the CSR and needs the exact counts)
+        // (no postings for this index: the partition starts from the CSR and needs the exact counts)
+        { const ks_fetch_seg f = ks_sketch_pending_seg(q); SE_CHECK(ks_stream_wait_fetch(ctx, &f, 1)); }
         SE_FINISH_PENDING();
     }
     if (n_q == 0 || n_t == 0) {
@@ -1216,7 +1217,11 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         const bool f10_fits = ix->fp_layout && pbits > 8 && q->part_s == 32u + (u32)ix->fp_shift;
         bool pre = pre_any && (q->part_s == 0 || f10_fits);
         const bool f10 = pre && q->part_s != 0;
-        if (q->pending && !pre) { SE_CHECK(ks_stream_wait(ctx)); SE_FINISH_PENDING(); }
+        if (q->pending && !pre) {
+            const ks_fetch_seg f = ks_sketch_pending_seg(q);
+            SE_CHECK(ks_stream_wait_fetch(ctx, &f, 1));
+            SE_FINISH_PENDING();
+        }
         u64 cap = n_q < (1u << 20) ? (1u << 20) : n_q;
         if (ctx->pair_cap_hint > cap) cap = ctx->pair_cap_hint; // a workload that matched heavily last time will again
         u64 n_pairs = 0, seg_cap = 0, seg_count[JN_SEGS];
@@ -1315,12 +1320,15 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 ks_timer_end(ctx);
                 SE_HIP(hipGetLastError());
                 // the segment counts (+ the flag word beside the first): one copy, strided when the list is segmented
-                if (n_segs == 1)
-                    SE_HIP(hipMemcpyAsync(ctx->h_pin, cursor, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-                else
-                    SE_HIP(hipMemcpy2DAsync(ctx->h_pin, 2 * sizeof(u64), cursor, (size_t)JN_CUR_STRIDE * sizeof(u64), 2 * sizeof(u64), JN_SEGS,
-                                            hipMemcpyDeviceToHost, ctx->stream));
-                SE_CHECK(ks_stream_wait(ctx));
+                // (the kernel that stamps the host's flag writes them to the pinned block itself — with the control block of a
+                // pending sketch — instead of a copy dispatch per block in front of it)
+                {
+                    ks_fetch_seg f[2];
+                    f[0] = ks_fetch_seg{cursor, (u32 *)ctx->h_pin, n_segs == 1 ? 1u : (u32)JN_SEGS, 4u, (u32)JN_CUR_STRIDE * 2u};
+                    int nf = 1;
+                    if (q->pending) f[nf++] = ks_sketch_pending_seg(q);
+                    SE_CHECK(ks_stream_wait_fetch(ctx, f, nf));
+                }
                 SE_FINISH_PENDING();
                 n_pairs = 0;
                 u64 seg_max = 0;
@@ -1401,10 +1409,8 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         const u32 gp = (u32)((n_pairs + 255) / 256);
         const u32 pf_tiles = (u32)((n_pairs + PF_TILE - 1) / PF_TILE);
         u32 *nrows_dev = nullptr;
-        if (fused) { // status words, the ticket pair and the row count in one block: one memset, one copy back
-            SE_CHECK(ks_alloc(ctx, (u64 **)&pf_status, (size_t)pf_tiles + 2));
-            pf_ticket = (u32 *)(pf_status + pf_tiles);
-            nrows_dev = pf_ticket + 2;
+        if (fused) { // status words, the ticket pair and the row count in one block WITH the two row arrays the pass adds into
+                     // (allocated below, per attempt): one memset, one read-back
         } else {
             SE_CHECK(ks_alloc(ctx, &d_nrows, 1));
             nrows_dev = d_nrows;
@@ -1422,17 +1428,25 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         u32 n_rows = 0;
         for (int attempt = 0; attempt < 3; attempt++) { // (repeats: more rows than the guess; a look-back that gave up)
             SE_CHECK(ks_alloc(ctx, &H->d_qid, (size_t)rows_cap)); SE_CHECK(ks_alloc(ctx, &H->d_tid, (size_t)rows_cap));
-            SE_CHECK(ks_alloc(ctx, &H->d_isect, (size_t)rows_cap)); SE_CHECK(ks_alloc(ctx, &H->d_nw, (size_t)rows_cap));
-            SE_HIP(hipMemsetAsync(H->d_isect, 0, (size_t)rows_cap * sizeof(u32), ctx->stream));
-            SE_HIP(hipMemsetAsync(H->d_nw, 0, (size_t)rows_cap * sizeof(u64), ctx->stream));
+            {
+                // n_weighted (u64) | status words + ticket pair + row count (u64) | intersect (u32): zeroed together
+                const size_t st_words = fused ? (size_t)pf_tiles + 2 : 0, is_words = ((size_t)rows_cap + 1) / 2;
+                SE_CHECK(ks_alloc(ctx, &H->d_block, (size_t)rows_cap + st_words + is_words));
+                H->d_nw = H->d_block;
+                H->d_isect = (u32 *)(H->d_block + rows_cap + st_words);
+                if (fused) {
+                    pf_status = (unsigned long long *)(H->d_block + rows_cap);
+                    pf_ticket = (u32 *)(pf_status + pf_tiles);
+                    nrows_dev = pf_ticket + 2;
+                }
+                SE_HIP(hipMemsetAsync(H->d_block, 0, ((size_t)rows_cap + st_words + is_words) * sizeof(u64), ctx->stream));
+            }
             if (fused) {
-                SE_HIP(hipMemsetAsync(pf_status, 0, ((size_t)pf_tiles + 2) * sizeof(u64), ctx->stream));
                 ks_timer_begin(ctx, "pair_rows");
                 hipLaunchKernelGGL(k_pair_rows_fused, dim3(pf_tiles), dim3(PF_THREADS), 0, ctx->stream, (const u64 *)pk, n_pairs, H->d_qid, H->d_tid,
                                    H->d_isect, (unsigned long long *)H->d_nw, tbits, abits, (u32)rows_cap, pf_status, pf_ticket, nrows_dev,
                                    (ctx->rows_use_ticket || ks_dbg(ctx, KS_DBG_ROWS_TICKET)) ? 1 : 0);
                 ks_timer_end(ctx);
-                SE_HIP(hipMemcpyAsync(ctx->h_pin + 1, pf_ticket, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream)); // ticket pair + row count
             } else {
                 ks_timer_begin(ctx, "pair_reduce");
                 hipLaunchKernelGGL(k_pair_reduce, dim3(gp), dim3(256), 0, ctx->stream, (const u64 *)pk, (const u32 *)pv, (const u32 *)heads,
@@ -1440,9 +1454,13 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 ks_timer_end(ctx);
             }
             SE_HIP(hipGetLastError());
-            if (!fused) SE_HIP(hipMemcpyAsync(ctx->h_pin + 2, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-            SE_CHECK(ks_scan_status_fetch(ctx));
-            SE_CHECK(ks_stream_wait(ctx));
+            {
+                ks_fetch_seg f[2];
+                f[0] = fused ? ks_fetch_words(pf_ticket, ctx->h_pin + 1, 4) // ticket pair + row count
+                             : ks_fetch_words(d_nrows, ctx->h_pin + 2, 1);
+                const int nf = ks_scan_status_seg(ctx, &f[1]) ? 2 : 1;
+                SE_CHECK(ks_stream_wait_fetch(ctx, f, nf));
+            }
             SE_CHECK(ks_scan_status_check(ctx));
             bool gave_up = fused && ((u32 *)(ctx->h_pin + 1))[1] != 0;
             if (fused && ks_dbg(ctx, KS_DBG_FORCE_ROWS_TICKET_RETRY) && !ctx->rows_use_ticket) gave_up = true; // (tests)
@@ -1455,8 +1473,8 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 if (n_rows <= rows_cap) break;
                 rows_cap = n_rows;
             }
-            ks_pool_free(ctx, H->d_qid); ks_pool_free(ctx, H->d_tid); ks_pool_free(ctx, H->d_isect); ks_pool_free(ctx, H->d_nw);
-            H->d_qid = H->d_tid = H->d_isect = nullptr; H->d_nw = nullptr;
+            ks_pool_free(ctx, H->d_qid); ks_pool_free(ctx, H->d_tid); ks_pool_free(ctx, H->d_block);
+            H->d_qid = H->d_tid = H->d_isect = nullptr; H->d_nw = nullptr; H->d_block = nullptr;
         }
         if (!H->d_qid) { st = ks_fail(ctx, KS_ERR_HIP, "search: the row pass did not settle"); goto done; }
         H->n_hits = n_rows;
@@ -1469,7 +1487,7 @@ done:
     ks_pool_free(ctx, qk0); ks_pool_free(ctx, qk1); ks_pool_free(ctx, qv0); ks_pool_free(ctx, qv1);
     ks_pool_free(ctx, pk0); ks_pool_free(ctx, pk1); ks_pool_free(ctx, pv0); ks_pool_free(ctx, pv1);
     ks_pool_free(ctx, heads); ks_pool_free(ctx, d_nrows); ks_pool_free(ctx, row_start); ks_pool_free(ctx, cursor);
-    ks_pool_free(ctx, dir_q); ks_pool_free(ctx, pf_status);
+    ks_pool_free(ctx, dir_q); // (pf_status lies in the hit object's block)
     if (st != KS_OK || split) { (void)hipStreamSynchronize(ctx->stream); ks_hits_free(H); return st; }
     *out = H;
     return KS_OK;

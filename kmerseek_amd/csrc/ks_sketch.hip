@@ -1712,7 +1712,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     u64 *d_stats = nullptr;
     u32 *counts = nullptr;
     u32 *med_ids = nullptr, *long_ids = nullptr, *n_cls = nullptr, *tile_first = nullptr, *ticket = nullptr, *part_snap = nullptr;
-    unsigned long long *tile_status = nullptr;
+    unsigned long long *tile_status = nullptr, *tile_status_free = nullptr;
     u64 *slab64 = nullptr, *lg_hash = nullptr;
     u32 *slab32 = nullptr, *lg_abund = nullptr;
     u64 n_med = 0, n_long = 0, out_cap = 0; // (with a plan from max_seq_len: upper bounds, the true counts stay on the device)
@@ -1727,6 +1727,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     // is within 2x of the typical count, the launch takes it as its grid and the tiles beyond the device-side count return at
     // once.  (Worth ~20 us per call: small batches; a 1M-protein launch would not notice either way.)
     u64 pk_bound = 0;
+    u64 tiles_hint = 0; // tile status words that lie in the control block (zeroed with it)
     // compacting variant: bucket space = positions / c_div, span = residues per shared tile (see k_sketch_tiles<0, 1>)
     const bool compact = (variant & 1) && p->scaled >= 2 && !ks_dbg(ctx, KS_DBG_NO_COMPACT);
     const u32 c_div = compact ? (p->scaled < 64 ? p->scaled : 64u) : 1u;
@@ -1765,8 +1766,19 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         // every small word the host zeroes before / reads after the launches lives in ONE control block — one memset, one
         // device -> host copy per read-back instead of one per word (each is a dispatch of its own on this runtime):
         // [0, 20) statistics, [20] ticket + status bits, [21] medium / long counts, [22] tiles of a packed plan, [23] kept hashes
-        SK_CHECK(ks_alloc(ctx, &d_stats, SK_CTL_WORDS));
-        SK_HIPCHECK(hipMemsetAsync(d_stats, 0, SK_CTL_WORDS * sizeof(u64), ctx->stream));
+        // ... and the posting cursors (2048 x u32) and the tiles' status words sit right behind them: ONE allocation that the
+        // sketches object owns, ONE memset per call.  The tile count is known here when the plan needs no round trip (an
+        // upper bound otherwise: a launch with more tiles takes a status array of its own).
+        if (packed && planned && max_seq_len <= PK_MAX_LEN && !ks_dbg(ctx, KS_DBG_PLAN_SYNC)) {
+            const u64 b = n_res / (SK_MED_MAX - 15 - max_seq_len + 1) + pk_chunks + 1;
+            const u64 typical = n_res / 3800 + pk_chunks + 1;
+            if (b <= 2 * typical + 256 && b <= n_seqs) pk_bound = b;
+            else if (n_seqs <= 2 * typical + 256) pk_bound = n_seqs; // (a tile holds at least one sequence)
+        }
+        tiles_hint = packed ? pk_bound : n_res / cand.r[0] + 2;
+        SK_CHECK(ks_alloc(ctx, &S->ctl_block, (size_t)SK_CTL_WORDS + 1024 + tiles_hint + 1));
+        d_stats = S->ctl_block;
+        SK_HIPCHECK(hipMemsetAsync(d_stats, 0, ((size_t)SK_CTL_WORDS + 1024 + tiles_hint + 1) * sizeof(u64), ctx->stream));
         ticket = (u32 *)(d_stats + 20); n_cls = (u32 *)(d_stats + 21); d_ntiles = (u32 *)(d_stats + 22);
         u32 g = (n_seqs + 1023) / 1024;
         if (g > 512) g = 512;
@@ -1787,12 +1799,6 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             ks_timer_end(ctx);
             SK_HIPCHECK(hipGetLastError());
         }
-        if (packed && planned && max_seq_len <= PK_MAX_LEN && !ks_dbg(ctx, KS_DBG_PLAN_SYNC)) {
-            const u64 b = n_res / (SK_MED_MAX - 15 - max_seq_len + 1) + pk_chunks + 1;
-            const u64 typical = n_res / 3800 + pk_chunks + 1;
-            if (b <= 2 * typical + 256 && b <= n_seqs) pk_bound = b;
-            else if (n_seqs <= 2 * typical + 256) pk_bound = n_seqs; // (a tile holds at least one sequence)
-        }
         if (pk_bound) {
             real_max = max_seq_len;
             win_bound = n_res;
@@ -1801,8 +1807,10 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         } else if (!planned || packed) {
             // no upper bound on the sequence length from the caller: the plan (tile stride, deferred sequences, slab size)
             // comes from the batch itself, at the price of one device -> host round trip before the tiles are launched
-            SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, SK_CTL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-            SK_CHECK(ks_stream_wait(ctx));
+            {
+                const ks_fetch_seg f = ks_fetch_words(d_stats, ctx->h_pin, SK_CTL_WORDS * 2);
+                SK_CHECK(ks_stream_wait_fetch(ctx, &f, 1));
+            }
             win_bound = ctx->h_pin[0];
             if (packed) pk_n_tiles = *(u32 *)(ctx->h_pin + 22);
             if (ctx->h_pin[1] > 0xfffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "sequence longer than 2^32 residues"); goto done; }
@@ -1882,8 +1890,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             // (+ SK_TILE spare slots behind the last region: where a tile drops a digit that does not fit its region)
             SK_CHECK(ks_alloc(ctx, &S->part_keys, (size_t)(cap * n_segs) + SK_TILE));
             SK_CHECK(ks_alloc(ctx, &S->part_vals, (size_t)(cap * n_segs) + SK_TILE));
-            SK_CHECK(ks_alloc(ctx, &S->part_len, 2048));
-            SK_HIPCHECK(hipMemsetAsync(S->part_len, 0, 2048 * sizeof(u32), ctx->stream));
+            S->part_len = (u32 *)(S->ctl_block + SK_CTL_WORDS); // (zeroed with the control block)
             A.part_keys = S->part_keys; A.part_vals = S->part_vals; A.part_cursor = S->part_len; A.part_cap = cap;
             A.part_K = S->part_K; A.part_mask = S->part_regions - 1; A.part_sub_shift = S->part_sub_shift;
             A.part_kshift = (S->part_K & (S->part_K - 1)) == 0 && S->part_K > 1 ? 32u - (u32)__builtin_ctz(S->part_K) : 0u;
@@ -1940,8 +1947,14 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         // ---- shared tiles: hash + sort/unique + CSR placement in one kernel (decoupled look-back across tiles)
         const u64 n_tiles = packed ? pk_n_tiles : n_res / tile_R + 1;
         if (n_tiles > 0x7ffffff0ULL) { st = ks_fail(ctx, KS_ERR_INVALID_ARG, "batch too large"); goto done; }
-        SK_CHECK(ks_alloc(ctx, &tile_status, (size_t)n_tiles + 1));
-        SK_HIPCHECK(hipMemsetAsync(tile_status, 0, (size_t)n_tiles * sizeof(unsigned long long), ctx->stream));
+        unsigned long long *tile_status_own = nullptr;
+        if (n_tiles <= tiles_hint) tile_status = (unsigned long long *)(S->ctl_block + SK_CTL_WORDS + 1024); // (zeroed with the control block)
+        else {
+            SK_CHECK(ks_alloc(ctx, &tile_status_own, (size_t)n_tiles + 1));
+            tile_status = tile_status_own;
+            SK_HIPCHECK(hipMemsetAsync(tile_status, 0, (size_t)n_tiles * sizeof(unsigned long long), ctx->stream));
+        }
+        tile_status_free = tile_status_own;
         if (!packed) {
             SK_CHECK(ks_alloc(ctx, &tile_first, (size_t)n_tiles + 1));
             ks_timer_begin(ctx, "tile_plan");
@@ -2016,15 +2029,17 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             SK_HIPCHECK(hipGetLastError());
             // total + look-back error flag to the host
             if (allow_defer && attempt == 0 && (pk_bound || (planned && !packed)) && !ks_dbg(ctx, KS_DBG_FORCE_TICKET_RETRY)) {
-                // the caller's next wait on this stream (the search's) stands in for this one: the control block is copied to
-                // its own pinned words, everything of this call that is freed below is reused in stream order
-                SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin + KS_PIN_SKETCH, d_stats, SK_CTL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+                // the caller's next wait on this stream (the search's) stands in for this one and brings the control block along
+                // (ks_sketch_pending_seg); everything else of this call that is freed below is reused in stream order
+                S->pend_stats = d_stats;
                 S->pending = 1; S->pend_out_cap = out_cap; S->pend_max_seq_len = max_seq_len; S->pend_planned = planned ? 1 : 0;
                 S->n_hashes = out_cap; // (an upper bound until ks_sketch_finish_pending)
                 break;
             }
-            SK_HIPCHECK(hipMemcpyAsync(ctx->h_pin, d_stats, SK_CTL_WORDS * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-            SK_CHECK(ks_stream_wait(ctx));
+            {
+                const ks_fetch_seg f = ks_fetch_words(d_stats, ctx->h_pin, SK_CTL_WORDS * 2);
+                SK_CHECK(ks_stream_wait_fetch(ctx, &f, 1));
+            }
             u32 &status_w = ((u32 *)(ctx->h_pin + 20))[1];
             if (attempt == 0 && !A.use_ticket && ks_dbg(ctx, KS_DBG_FORCE_TICKET_RETRY)) status_w |= 1u; // exercises the repeat
             if (!(status_w & 1u) || A.use_ticket) break;
@@ -2046,15 +2061,15 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             if (S->n_hashes > out_cap) { *redo = 2; goto done; } // more kept hashes than the bounded outputs hold
             if (status & 2u) { // a region overflowed (skewed hashes) or a tile could not code its sequences: no postings,
                                // ks_search repartitions from the CSR instead
-                ks_pool_free(ctx, S->part_keys); ks_pool_free(ctx, S->part_vals); ks_pool_free(ctx, S->part_len);
+                ks_pool_free(ctx, S->part_keys); ks_pool_free(ctx, S->part_vals); // (part_len lies in the control block)
                 S->part_keys = nullptr; S->part_vals = nullptr; S->part_len = nullptr; S->part_pbits = 0;
             }
         }
     }
 
 done:
-    ks_pool_free(ctx, counts); ks_pool_free(ctx, tile_first); ks_pool_free(ctx, tile_status); ks_pool_free(ctx, part_snap);
-    ks_pool_free(ctx, d_stats); ks_pool_free(ctx, med_ids); ks_pool_free(ctx, long_ids);
+    ks_pool_free(ctx, counts); ks_pool_free(ctx, tile_first); ks_pool_free(ctx, tile_status_free); ks_pool_free(ctx, part_snap);
+    ks_pool_free(ctx, med_ids); ks_pool_free(ctx, long_ids);
     ks_pool_free(ctx, slab64); ks_pool_free(ctx, slab32); ks_pool_free(ctx, lg_hash); ks_pool_free(ctx, lg_abund);
     ks_pool_free(ctx, pk_tiles); ks_pool_free(ctx, pk_cnt); ks_pool_free(ctx, tile_g0);
     if (st != KS_OK || *redo) {
@@ -2068,12 +2083,17 @@ done:
 #undef SK_HIPCHECK
 }
 
+ks_fetch_seg ks_sketch_pending_seg(const ks_sketches *S) {
+    return ks_fetch_words(S->pend_stats, S->ctx->h_pin + KS_PIN_SKETCH, SK_CTL_WORDS * 2);
+}
+
 int ks_sketch_finish_pending(ks_sketches *S, int *redo) {
     *redo = 0;
     if (!S || !S->pending) return KS_OK;
     ks_ctx *ctx = S->ctx;
     const u64 *stats = ctx->h_pin + KS_PIN_SKETCH;
     S->pending = 0;
+    S->pend_stats = nullptr; // (lies in the control block, which the object keeps)
     S->n_hashes = stats[23];
     if (S->pend_planned) {
         S->n_windows = stats[0];
