@@ -415,7 +415,10 @@ __global__ __launch_bounds__(256) void k_index_finish(const u64 *keys, const u32
 }
 
 #ifndef JN_DIR
-#define JN_DIR 2048
+#define JN_DIR 4096
+#endif
+#ifndef JN_PROBES
+#define JN_PROBES 4 // entries of a directory slot a query looks at without a loop (more in the slot: the searched path)
 #endif
 #define JN_SEGS 64       // most segments (cursors) of the pair list
 #define JN_CUR_STRIDE 64 // u64 words between two cursors
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
     const u64 *qkeys, const u32 *qids, const u32 *ifp, const ks_post *ipost, const ks_bmeta *bmeta, const u64 *q_lo, const u64 *q_hi,
     const u64 *dir_t, u64 *pair_keys, u32 *pair_vals, u64 cap, unsigned long long *cursors, u32 seg_mask, int tbits, int abits,
     int fp_shift) {
-    __shared__ u32 lk[JN_CAP];
+    __shared__ u32 lk[JN_CAP + JN_PROBES]; // (+ slack: the probes of a slot read JN_PROBES entries whatever it holds)
     __shared__ unsigned short ldir[JN_DIR + 2]; // ldir[j] = staged fingerprints whose slot (jn_slot) is < j
     __shared__ u32 wlist[JN_THREADS / 64][JN_WLIST]; // per-wave candidate list: query slot | index posting << 13
     __shared__ u64 wlist_h[JN_THREADS / 64][JN_WLIST]; // ... and the query's hash
@@ -615,16 +618,34 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
                 const u32 f = QF.fp(h[e], kbase, fp_shift);
                 const u32 sl = jn_slot(f, dirM);
                 const u32 d0 = ldir[sl], d1 = ldir[sl + 1];
-                // the slot holds n / JN_DIR fingerprints on average — none or one, mostly: look at them all; a slot crowded by
-                // repeats of one hash is searched
+                // The slot holds n / JN_DIR fingerprints on average — one, give or take: its first JN_PROBES entries are read at once
+                // (no loop, no wait between dependent LDS reads: the per-entry loop this replaces ran for the fullest slot among
+                // the wave's 64 queries and waited for LDS in every turn) and compared under the slot's count; equal fingerprints
+                // are neighbours, so the matches form one run.  A slot with more entries (a crowded slot, a hash many targets share)
+                // is walked or searched.
                 u32 lo = d0, c = 0;
                 if (i < nq && QF.in_range(h[e], kbase)) { // (a hash below the bucket's first key matches nothing)
-                    if (d1 - d0 <= 8u) {
-                        for (u32 r = d0; r < d1; r++)
-                            if (lk[r] == f) { lo = c ? lo : r; c++; }
-                    } else {
-                        lo = d0 + jn_lower_bound_lds(lk + d0, d1 - d0, f);
-                        while (lo + c < d1 && lk[lo + c] == f) c++;
+                    const u32 cnt = d1 - d0;
+                    u32 pv[JN_PROBES];
+#pragma unroll
+                    for (int j = 0; j < JN_PROBES; j++) pv[j] = lk[d0 + j];
+                    u32 first = JN_PROBES;
+#pragma unroll
+                    for (int j = JN_PROBES - 1; j >= 0; j--) {
+                        const bool mt = (u32)j < cnt && pv[j] == f;
+                        c += mt ? 1u : 0u;
+                        first = mt ? (u32)j : first;
+                    }
+                    lo = d0 + (c ? first : 0u);
+                    if (cnt > (u32)JN_PROBES) { // rare: start over on the whole slot
+                        lo = d0; c = 0;
+                        if (cnt <= 8u) {
+                            for (u32 r = d0; r < d1; r++)
+                                if (lk[r] == f) { lo = c ? lo : r; c++; }
+                        } else {
+                            lo = d0 + jn_lower_bound_lds(lk + d0, cnt, f);
+                            while (lo + c < d1 && lk[lo + c] == f) c++;
+                        }
                     }
                 }
                 info[e] = lo | (c << 16);
@@ -769,10 +790,10 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
 #define JS_DIR 1024   // directory slots over the table
 #define JS_WLIST 128  // candidates a wave lists per pass
 KS_DEV u32 js_slot(u32 f, u32 mul) { // slot of a fingerprint: the bucket's JN_DIR slot mapping, coarsened
-    const u32 j = __umulhi(f, mul) >> 1; // (JN_DIR / JS_DIR = 2)
+    const u32 j = __umulhi(f, mul) / (u32)(JN_DIR / JS_DIR);
     return j < (u32)JS_DIR - 1u ? j : (u32)JS_DIR - 1u;
 }
-static_assert(JN_DIR == 2 * JS_DIR, "js_slot halves the JN_DIR slot");
+static_assert(JN_DIR % JS_DIR == 0 && ((JN_DIR / JS_DIR) & (JN_DIR / JS_DIR - 1)) == 0, "js_slot coarsens the JN_DIR slot by a power of two");
 template <int F10>
 __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_join_sparse(
     const u64 *qkeys, const u32 *qids, const u32 *ifp, const ks_post *ipost, const ks_bmeta *bmeta, const u64 *q_lo, const u64 *q_hi,
