@@ -123,9 +123,13 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
         hipLaunchKernelGGL(k_bucket_dir, dim3((nb + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys, n, ix->pbits, K, ix->d_dir);
         ks_timer_end(ctx);
         IX_HIP(hipGetLastError());
-        // Big indexes (>= 2^JN_FP_PBITS join buckets) are joined on 4-byte fingerprints (streamed) + 16-byte postings (fetched per
-        // candidate match); the others keep the sorted columns (k_join_buckets_keys)
-        ix->fp_layout = ix->pbits >= JN_FP_PBITS || ks_dbg(ctx, KS_DBG_JOIN_FP);
+        // Indexes are joined on 4-byte fingerprints (streamed; a directory over them in LDS instead of a binary search) + 16-byte
+        // postings (fetched per candidate match).  Medium and small hp indexes keep the sorted columns (k_join_buckets_keys): with
+        // a two-letter alphabet most queries match, several times (200k x 200k hp k = 24: 49 M matches from 11 M query hashes), and
+        // the confirmation fetches then cost more than the searches save (0.885 vs 0.845 ms there; protein / dayhoff: 100k x 100k
+        // k = 10 join 0.262 -> 0.194 ms, configs[1] 35 -> 29 us, configs[2] 56 -> 46 us).  KS_DEBUG_JOIN_FP = 1 / 0 forces either.
+        ix->fp_layout = ix->pbits >= JN_FP_PBITS || t->params.moltype != KS_HP;
+        if (const char *f = ks_dbg(ctx, KS_DBG_JOIN_FP)) ix->fp_layout = atoi(f) != 0 || ix->pbits >= JN_FP_PBITS;
         if (ix->fp_layout) {
         IX_CHECK(ks_alloc(ctx, &ix->d_fp, (size_t)(n ? n : 1)));
         IX_CHECK(ks_alloc(ctx, &ix->d_post, (size_t)(n ? n : 1)));

@@ -1022,8 +1022,10 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             const u64 at = gaddr[sk_digit(hh, A.part_K, A.part_kshift, A.part_mask)] + i;
 #ifndef SK_NO_POST_STORES // (diagnostic builds only: the kernel's time without the posting stores)
             const u32 qid = s_first + qrel[i];
-            if (A.part_s) { // (uniform) 10-byte postings
-                A.part_keys[at] = (hh & ~(0xffULL << A.part_s)) | ((u64)(qid & 0xffu) << A.part_s);
+            if (A.part_s) { // (uniform) 10-byte postings; the field lies in the high word (part_s >= 48): one shift + one bit-field insert
+                const u32 sh = A.part_s - 32u, fm = 0xffu << sh;
+                const u32 hi = (((u32)(hh >> 32)) & ~fm) | ((qid << sh) & fm);
+                A.part_keys[at] = ((u64)hi << 32) | (u32)hh;
                 ((u16 *)A.part_vals)[at] = (u16)(qid >> 8);
             } else {
                 A.part_keys[at] = hh;

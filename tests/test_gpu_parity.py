@@ -631,7 +631,9 @@ def test_bucket_scatter_overflow_falls_back_to_dense_partition(ctx):
     Q = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
     assert Q.has_postings
     H = ctx.search(ix, Q)
-    assert H.partition_path == 2  # bucket scatter overflowed, dense pass over the regions took over
+    # bucket scatter overflowed: the dense pass over the regions took over (12-byte postings), or the partition from the CSR
+    # (10-byte postings — the index of a protein alphabet is in the fingerprint layout — are read by the scatter only)
+    assert H.partition_path == (3 if Q.posting_bytes == 10 else 2)
     got = H.to_host()
     assert (want[1] == 11).sum() >= 1500
     for g, w in zip(got, want):
@@ -967,8 +969,10 @@ def test_join_fingerprints_segments_and_retry_are_exact(ctx, monkeypatch, k, sca
             assert np.array_equal(g, w), label
         hits.free(); ix.free()
 
-    check("default (columns)")
-    monkeypatch.setenv("KS_DEBUG_JOIN_FP", "1")   # the layout of big indexes, on a small one
+    check("default")
+    monkeypatch.setenv("KS_DEBUG_JOIN_FP", "0")   # the sorted columns (what medium hp indexes keep), whatever the alphabet
+    check("columns")
+    monkeypatch.setenv("KS_DEBUG_JOIN_FP", "1")   # the fingerprint layout, whatever the alphabet
     monkeypatch.setenv("KS_DEBUG_JOIN_SPARSE", "0")
     check("fingerprints, staged index")
     monkeypatch.setenv("KS_DEBUG_JOIN_SPARSE", "1")   # the kernel of sparse buckets (query table, streamed index)
@@ -1041,7 +1045,7 @@ def test_join_kernels_agree_on_heavily_repeated_hashes(ctx, monkeypatch):
     assert len(want[0]) > 300 * 7000
     T = ctx.sketch_batch(t_res, t_off, k, scaled, mol)
     Q = ctx.sketch_batch(q_res, q_off, k, scaled, mol)
-    for label, env in (("key columns", {}), ("fingerprints, staged index", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "0"}),
+    for label, env in (("default", {}), ("key columns", {"KS_DEBUG_JOIN_FP": "0"}), ("fingerprints, staged index", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "0"}),
                        ("fingerprints, query table", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "1"}),
                        ("fingerprints, query table, segments", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "1", "KS_DEBUG_JOIN_SEGS": "1"}),
                        ("fingerprints, staged index, segments, coarse", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "0", "KS_DEBUG_JOIN_SEGS": "1",

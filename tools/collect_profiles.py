@@ -18,8 +18,8 @@ CONFIGS = ["c4_1m_protein_k10_s1", "c2_10k_protein_k7_s1", "c3_100k_dayhoff_k16_
 
 
 def one(pattern):
-    f = glob.glob(pattern, recursive=True)
-    return f[0] if f else None
+    f = glob.glob(pattern, recursive=True)  # (gpurun merges into gpurun_out/: files of earlier runs may still lie there)
+    return max(f, key=os.path.getmtime) if f else None
 
 
 def main():

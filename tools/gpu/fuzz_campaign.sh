@@ -1,6 +1,7 @@
 mkdir -p gpurun_out
 run() { name=$1; shift; env "$@" timeout -k 10 500 python tools/fuzz_parity.py --cases 350 --seed $SEED > gpurun_out/r3_fz_$name.log 2>&1; echo "$name rc=$? $(tail -1 gpurun_out/r3_fz_$name.log)"; }
 SEED=301 run default A=1
+SEED=315 run key_columns KS_DEBUG_JOIN_FP=0
 SEED=302 run fp_staged KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=0
 SEED=303 run fp_sparse KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=1
 SEED=304 run fp_sparse_segs_coarse KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=1 KS_DEBUG_JOIN_SEGS=1 KS_DEBUG_FP_COARSEN=18
@@ -12,3 +13,6 @@ SEED=310 run full_lists KS_DEBUG_QCAP=2
 SEED=311 run nopack KS_DEBUG_NO_PACK=1
 SEED=312 run nopack_full_lists KS_DEBUG_NO_PACK=1 KS_DEBUG_QCAP=1
 SEED=309 timeout -k 10 600 python tools/fuzz_parity.py --big --cases 20 --seed 309 > gpurun_out/r3_fz_big.log 2>&1; echo "big rc=$? $(tail -1 gpurun_out/r3_fz_big.log)"
+# big batches against an index in the fingerprint layout: 10-byte query postings at scaled = 1 (both fingerprint join kernels)
+SEED=313 KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=0 timeout -k 10 500 python tools/fuzz_parity.py --big --cases 12 --seed 313 > gpurun_out/r3_fz_big_fp_staged.log 2>&1; echo "big_fp_staged rc=$? $(tail -1 gpurun_out/r3_fz_big_fp_staged.log)"
+SEED=314 KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=1 timeout -k 10 500 python tools/fuzz_parity.py --big --cases 12 --seed 314 > gpurun_out/r3_fz_big_fp_sparse.log 2>&1; echo "big_fp_sparse rc=$? $(tail -1 gpurun_out/r3_fz_big_fp_sparse.log)"

@@ -8,7 +8,7 @@ import collections
 import csv
 import sys
 
-KERNELS = ["void k_sketch_tiles<0, 0", "void k_sketch_tiles<0, 1", "k_bucket_scatter", "k_join_buckets", "k_msd_local(",
+KERNELS = ["void k_sketch_tiles<0, 0", "void k_sketch_tiles<0, 1", "void k_bucket_scatter<", "void k_join_buckets<", "k_join_buckets_keys", "k_msd_local(",
            "void k_msd_scatter<256>", "void k_msd_scatter<512>", "k_kmerpos_tiles"]
 
 
