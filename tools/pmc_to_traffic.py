@@ -21,10 +21,13 @@ NAMES = {  # profiler kernel name prefix -> library timing name
     "void k_msd_scatter<512>": "msd_scatter.level2",
     "void k_msd_scatter<1024>": "msd_scatter.level2",
     "k_bucket_scatter": "bucket_scatter",
+    "void k_bucket_scatter<": "bucket_scatter",          # (template on the posting format since round 3)
     "void k_radix_scatter<unsigned int, 1>": "radix_scatter.qpart",
     "void k_radix_hist<1>": "radix_hist.qpart",
     "k_join_buckets": "join_buckets",
     "k_join_sparse": "join_buckets",
+    "void k_join_buckets<": "join_buckets",
+    "void k_join_sparse<": "join_buckets",
     "void k_radix_scatter<unsigned long, 0>": "radix_scatter.index",
 }
 
