@@ -532,6 +532,33 @@ def test_one_call_sketch_search_equals_the_two_calls(ctx, monkeypatch, k, scaled
             assert np.array_equal(g, w)
 
 
+def test_one_call_sketch_search_edge_batches(ctx):
+    """Empty batch, batch of sequences shorter than k (no windows), empty index, a single query: the one-call entry returns
+    what the two calls return."""
+    t_res, t_off = synth.proteome(500, stream=298)
+    ix = ctx.index_build(ctx.sketch_batch(t_res, t_off, 10, 1, "protein"))
+    cases = [ks.pack([]), ks.pack([b"ACDEF", b"", b"GHIKLMNPQ"]), ks.pack([bytes(t_res[int(t_off[3]):int(t_off[4])])])]
+    for q_res, q_off in cases:
+        nq = len(q_off) - 1
+        d_res, d_off = ctx.to_device(q_res if len(q_res) else np.zeros(16, np.uint8)), ctx.to_device(q_off)
+        mx = int((q_off[1:] - q_off[:-1]).max()) if nq else 1
+        Q2 = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, nq, len(q_res), max_seq_len=mx)
+        want = ctx.search(ix, Q2).to_host()
+        Q, H = ctx.sketch_search_device(ix, d_res.ptr, d_off.ptr, nq, len(q_res), max_seq_len=mx)
+        for g, w in zip(Q.to_host(), Q2.to_host()):
+            assert np.array_equal(g, w)
+        for g, w in zip(H.to_host(), want):
+            assert np.array_equal(g, w)
+    assert len(want[0]) >= 1 and want[1][0] == 3   # the single query is target 3
+    empty_ix = ctx.index_build(ctx.sketch_batch(*ks.pack([b"AC", b""]), 10, 1, "protein"))   # no k-mers: an index without postings
+    q_res, q_off = synth.queries(200, t_res, t_off, stream=299)
+    d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
+    Q, H = ctx.sketch_search_device(empty_ix, d_res.ptr, d_off.ptr, 200, len(q_res), max_seq_len=int((q_off[1:] - q_off[:-1]).max()))
+    assert H.count == 0
+    for g, w in zip(Q.to_host(), oracle.sketch_batch(q_res, q_off, 10, 1, "protein", n_threads=4)):
+        assert np.array_equal(g, w)
+
+
 def test_one_call_sketch_search_repeats_plainly_when_the_sketch_must(ctx, monkeypatch):
     """What the deferred read-back finds out too late — dropped postings (skewed hashes), a compacting tile that overflowed,
     bounded outputs that were too small, a look-back that gave up, a wrong max_seq_len — ends in the plain two calls (or in the
