@@ -320,7 +320,16 @@ int ks_index_sort_partitioned(ks_ctx *ctx, const u64 *keys_in, const u64 *vals_i
 // Match-list sort in three moves whatever the key width (ks_msd.hip): two exact MSD partition levels of 8 bits + in-LDS sort of the
 // 65,536 buckets.  Sorts `ka` in place on key bits [lo_bit, lo_bit + nbits); kb = scratch.  *done = 0: not applicable (small list /
 // narrow key / KS_DEBUG_PAIRS_LSD), the caller takes the LSD passes.
-int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbits, int *done);
+// segs != NULL: the list lies in ka in segs->n segments seg_cap records apart, count[s] of them filled (the join's segmented
+// pair list): the first partition level reads it as it lies — no copy that makes it dense first
+#define KS_MSD_MAX_SEGS 64
+struct ks_msd_segs {
+    u32 n;
+    u32 tile_start[KS_MSD_MAX_SEGS + 1]; // first level-1 tile of every segment (the last entry: all tiles)
+    u32 count[KS_MSD_MAX_SEGS];
+    u64 seg_cap;
+};
+int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbits, int *done, const ks_msd_segs *segs = nullptr);
 int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_in, u64 *ka, u64 *va, u64 *kb, u64 *vb,
                       u64 n, const int *shifts, int n_shifts, u64 **keys_out, u64 **vals_out);
 

@@ -21,6 +21,7 @@
 #define MS_IPT 16
 #define MS_TILE (MS_THREADS * MS_IPT) // 8192 records per tile of a partition pass
 #define MS_WAVES (MS_THREADS / 64)
+static_assert(MS_TILE == 8192, "ks_search.hip counts the level-1 tiles of a segmented list in units of 8192 records");
 #define MS_SUB 8u // level-1 sub-histograms
 
 // Digit of a record at a level: NB = 256 -> 8 bits at `shift`; NB = 512 -> the 16 bits at `shift` RELATIVE to the tile's
@@ -39,17 +40,37 @@ KS_DEV u32 ms_base(const u64 *keys, u64 tile_base, int shift, u32 mask, int bits
     else return (((u32)(keys[tile_base] >> shift) & mask) >> bits2) << bits2;
 }
 
+// where tile `t` of a level-1 pass reads: records [base, base + nvalid) of the list — dense, or in the join's segments
+template <int SEG>
+KS_DEV void ms_tile_range(u32 t, u64 n, const ks_msd_segs &S, u64 *base, u32 *nvalid) {
+    if constexpr (SEG == 0) {
+        *base = (u64)t * MS_TILE;
+        *nvalid = (n - *base) < MS_TILE ? (u32)(n - *base) : MS_TILE;
+    } else {
+        u32 lo = 0, hi = S.n; // tile_start[lo] <= t < tile_start[hi] (uniform: scalar loads of the kernel arguments)
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (S.tile_start[mid] <= t) lo = mid; else hi = mid;
+        }
+        const u64 off = (u64)(t - S.tile_start[lo]) * MS_TILE;
+        *base = (u64)lo * S.seg_cap + off;
+        *nvalid = ((u64)S.count[lo] - off) < MS_TILE ? (u32)((u64)S.count[lo] - off) : MS_TILE;
+    }
+}
+
 // hist[bin] += records of this tile per bin
 // (`sub_stride`: level 1 keeps MS_SUB histograms, tile t counting in number t mod MS_SUB — atomics on ONE address are served
 // one at a time, ~12 ns each, and a level-1 bin would take one from every tile; 0 = one histogram)
-template <int NB>
-__global__ __launch_bounds__(MS_THREADS) void k_msd_hist(const u64 *keys, u64 n, int shift, u32 *hist, u32 mask, int bits2, u32 sub_stride) {
+template <int NB, int SEG = 0>
+__global__ __launch_bounds__(MS_THREADS) void k_msd_hist(const u64 *keys, u64 n, int shift, u32 *hist, u32 mask, int bits2, u32 sub_stride,
+                                                         ks_msd_segs segs) {
     __shared__ u32 bins[NB];
     const u32 tid = threadIdx.x;
     hist += (blockIdx.x & (MS_SUB - 1u)) * sub_stride;
     for (u32 i = tid; i < NB; i += MS_THREADS) bins[i] = 0;
-    const u64 tile_base = (u64)blockIdx.x * MS_TILE;
-    const u32 nvalid = (n - tile_base) < MS_TILE ? (u32)(n - tile_base) : MS_TILE;
+    u64 tile_base;
+    u32 nvalid;
+    ms_tile_range<SEG>(blockIdx.x, n, segs, &tile_base, &nvalid);
     const u32 base = ms_base<NB>(keys, tile_base, shift, mask, bits2);
     __syncthreads();
 #pragma unroll
@@ -83,9 +104,9 @@ __global__ __launch_bounds__(256) void k_msd_scan256(u32 *hist, u32 n_sub) {
 // One partition pass: record -> bin cursor (exact sizes).  Ranks inside (tile, bin) are LDS atomic returns, one global
 // atomic per (tile, non-empty bin) reserves the slice, records leave through LDS in bin order so that every bin is
 // written as one contiguous run.
-template <int NB>
+template <int NB, int SEG = 0>
 __global__ __launch_bounds__(MS_THREADS, 2) void k_msd_scatter(const u64 *kin, u64 *kout, u64 n, int shift, u32 *cur, u32 mask, int bits2,
-                                                               u32 sub_stride) {
+                                                               u32 sub_stride, ks_msd_segs segs) {
     __shared__ u32 cnt[NB];
     __shared__ u32 dstart[NB];
     __shared__ u32 gbase[NB];
@@ -93,8 +114,9 @@ __global__ __launch_bounds__(MS_THREADS, 2) void k_msd_scatter(const u64 *kin, u
     __shared__ __attribute__((aligned(16))) u64 stage[MS_TILE];
     const u32 tid = threadIdx.x;
     const u32 bid = ks_xcd_block(); // neighbouring tiles (whose runs meet in the same cache lines) share one L2
-    const u64 tile_base = (u64)bid * MS_TILE;
-    const u32 nvalid = (n - tile_base) < MS_TILE ? (u32)(n - tile_base) : MS_TILE;
+    u64 tile_base;
+    u32 nvalid;
+    ms_tile_range<SEG>(bid, n, segs, &tile_base, &nvalid);
     cur += (bid & (MS_SUB - 1u)) * sub_stride; // (the cursors of this tile's sub-histogram, see k_msd_hist)
     for (u32 i = tid; i < NB; i += MS_THREADS) cnt[i] = 0;
     const u32 base = ms_base<NB>(kin, tile_base, shift, mask, bits2);
@@ -398,7 +420,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_msd_local_big(u64 *keys, u64 *sc
 
 // Sorts the n packed match records of `ka` on their key bits [lo_bit, lo_bit + nbits) (kb: scratch of the same size).
 // *done = 0 when the list is too small / the key too narrow for this path to pay (the caller takes the LSD sort).
-int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbits, int *done) {
+int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbits, int *done, const ks_msd_segs *segs) {
     *done = 0;
     if (nbits <= 16 || n < 65536 || n >= 0xffffffffULL || ks_dbg(ctx, KS_DBG_PAIRS_LSD)) return KS_OK;
     // level 2 is as wide as it takes for ~768 records per bucket (0 .. 8 bits): a short list does not pay 65,536 buckets
@@ -413,7 +435,10 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
     if (nbits - 8 - bits2 <= 0) bits2 = nbits - 9 > 0 ? nbits - 9 : 0; // (at least one bit left for the local sort)
     const int shift1 = lo_bit + nbits - 8, shift2 = shift1 - bits2;
     const u32 mask2 = (1u << (8 + bits2)) - 1u, n_buckets = 1u << (8 + bits2);
-    const u32 n_tiles = (u32)((n + MS_TILE - 1) / MS_TILE);
+    const u32 n_tiles = (u32)((n + MS_TILE - 1) / MS_TILE);             // of a dense list (level 2 always reads one)
+    const u32 n_tiles1 = segs ? segs->tile_start[segs->n] : n_tiles;    // of level 1
+    ks_msd_segs no_segs;
+    no_segs.n = 0;
     u32 lds_cap = ML_CAP;
     if (const char *f = ks_dbg(ctx, KS_DBG_MSD_LDS_CAP)) { // exercises the large-bucket paths on small inputs
         const u32 v = (u32)atoi(f);
@@ -433,28 +458,31 @@ int ks_sort_pairs_msd(ks_ctx *ctx, u64 *ka, u64 *kb, u64 n, int lo_bit, int nbit
     if (st == KS_OK) {
         (void)hipMemsetAsync(blk, 0, n_zero * sizeof(u32), ctx->stream);
         ks_timer_begin(ctx, "msd_hist");
-        hipLaunchKernelGGL((k_msd_hist<256>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, n, shift1, off1, 255u, 0, sub_stride);
+        if (segs) hipLaunchKernelGGL((k_msd_hist<256, 1>), dim3(n_tiles1), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, n, shift1, off1, 255u, 0, sub_stride, *segs);
+        else hipLaunchKernelGGL((k_msd_hist<256, 0>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, n, shift1, off1, 255u, 0, sub_stride, no_segs);
         ks_timer_end(ctx);
         ks_timer_begin(ctx, "msd_scan");
         hipLaunchKernelGGL(k_msd_scan256, dim3(1), dim3(256), 0, ctx->stream, off1, n_sub);
         ks_timer_end(ctx);
         ks_timer_begin(ctx, "msd_scatter");
-        hipLaunchKernelGGL((k_msd_scatter<256>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, kb, n, shift1, off1, 255u, 0,
-                           sub_stride);
+        if (segs) hipLaunchKernelGGL((k_msd_scatter<256, 1>), dim3(n_tiles1), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, kb, n, shift1, off1, 255u, 0,
+                                     sub_stride, *segs);
+        else hipLaunchKernelGGL((k_msd_scatter<256, 0>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)ka, kb, n, shift1, off1, 255u, 0,
+                                sub_stride, no_segs);
         ks_timer_end(ctx);
         sorted_in = kb;
     }
     const u32 *off = off1;
     if (st == KS_OK && bits2 > 0) {
         ks_timer_begin(ctx, "msd_hist");
-        if (bits2 <= 8) hipLaunchKernelGGL((k_msd_hist<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, n, shift2, off2, mask2, bits2, 0u);
-        else hipLaunchKernelGGL((k_msd_hist<1024>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, n, shift2, off2, mask2, bits2, 0u);
+        if (bits2 <= 8) hipLaunchKernelGGL((k_msd_hist<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, n, shift2, off2, mask2, bits2, 0u, no_segs);
+        else hipLaunchKernelGGL((k_msd_hist<1024>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, n, shift2, off2, mask2, bits2, 0u, no_segs);
         ks_timer_end(ctx);
         st = ks_scan_u32_inplace(ctx, off2, n_buckets, nullptr);
         if (st == KS_OK) {
             ks_timer_begin(ctx, "msd_scatter");
-            if (bits2 <= 8) hipLaunchKernelGGL((k_msd_scatter<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, ka, n, shift2, off2, mask2, bits2, 0u);
-            else hipLaunchKernelGGL((k_msd_scatter<1024>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, ka, n, shift2, off2, mask2, bits2, 0u);
+            if (bits2 <= 8) hipLaunchKernelGGL((k_msd_scatter<512>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, ka, n, shift2, off2, mask2, bits2, 0u, no_segs);
+            else hipLaunchKernelGGL((k_msd_scatter<1024>), dim3(n_tiles), dim3(MS_THREADS), 0, ctx->stream, (const u64 *)kb, ka, n, shift2, off2, mask2, bits2, 0u, no_segs);
             ks_timer_end(ctx);
             sorted_in = ka;
             off = off2;

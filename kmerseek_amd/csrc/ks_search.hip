@@ -1404,7 +1404,23 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         // sort matches by (qid, tid) on the live id bits only
         SE_CHECK(ks_alloc(ctx, &pk1, (size_t)n_pairs));
         if (!packed) SE_CHECK(ks_alloc(ctx, &pv1, (size_t)n_pairs));
-        if (n_segs > 1) { // the segments -> one dense list (then the roles of the two buffers swap: the segmented one is the scratch)
+        // Packed records go into the match sort as they lie: its first partition level reads the segments in place.  Only a list
+        // that sort declines (short lists, narrow keys: the LSD passes) or unpacked records are made dense by a copy first.
+        int msd = 0;
+        if (n_segs > 1 && packed) {
+            static_assert(JN_SEGS <= KS_MSD_MAX_SEGS, "segment table of the match sort");
+            ks_msd_segs sg;
+            sg.n = n_segs; sg.seg_cap = seg_cap;
+            u32 t = 0;
+            for (u32 s_ = 0; s_ < n_segs; s_++) {
+                sg.tile_start[s_] = t; sg.count[s_] = (u32)seg_count[s_];
+                t += (u32)((seg_count[s_] + 8191) / 8192); // (MS_TILE records per level-1 tile, ks_msd.hip)
+            }
+            sg.tile_start[n_segs] = t;
+            for (u32 s_ = n_segs + 1; s_ <= KS_MSD_MAX_SEGS; s_++) sg.tile_start[s_] = t;
+            SE_CHECK(ks_sort_pairs_msd(ctx, pk0, pk1, n_pairs, abits, tbits + qbits, &msd, &sg));
+        }
+        if (n_segs > 1 && !msd) { // the segments -> one dense list (then the roles of the two buffers swap: the segmented one is the scratch)
             jn_seg_table tab;
             u64 acc = 0;
             for (u32 s_ = 0; s_ < n_segs; s_++) { tab.prefix[s_] = acc; acc += seg_count[s_]; }
@@ -1426,8 +1442,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
             for (int sh = 0; sh < tbits + qbits; sh += 8) shifts[ns++] = abits + sh;
             // the match list (pk0, pv0) is scratch from here on: ping-pong with (pk1, pv1).  Packed records: three moves
             // (two exact MSD partition levels + in-LDS bucket sort, ks_msd.hip) instead of one per 8 key bits
-            int msd = 0;
-            if (packed) SE_CHECK(ks_sort_pairs_msd(ctx, pk0, pk1, n_pairs, abits, tbits + qbits, &msd));
+            if (packed && !msd) SE_CHECK(ks_sort_pairs_msd(ctx, pk0, pk1, n_pairs, abits, tbits + qbits, &msd));
             if (msd) pk = pk0;
             else if (packed) SE_CHECK(ks_radix_sort_keys(ctx, KS_SORT_PAIRS, pk0, pk0, pk1, n_pairs, shifts, ns, &pk));
             else SE_CHECK(ks_radix_sort_u32(ctx, KS_SORT_PAIRS, pk0, pv0, pk0, pv0, pk1, pv1, n_pairs, shifts, ns, &pk, &pv));
