@@ -186,6 +186,9 @@ int ks_sketch_queries_device(ks_ctx *ctx, const ks_index *index, const uint8_t *
 int ks_sketch_search_device(ks_ctx *ctx, const ks_index *index, const uint8_t *d_residues,
                             const uint64_t *d_seq_offsets, uint32_t n_seqs, uint64_t n_residues,
                             uint32_t max_seq_len, ks_sketches **sketches_out, ks_hits **hits_out);
+/* The same from host arrays (the layout ks_sketch_batch takes): upload, sketch, search. */
+int ks_sketch_search(ks_ctx *ctx, const ks_index *index, const uint8_t *residues, const uint64_t *seq_offsets,
+                     uint32_t n_seqs, ks_sketches **sketches_out, ks_hits **hits_out);
 
 uint32_t ks_sketches_n_seqs(const ks_sketches *s);
 uint64_t ks_sketches_n_hashes(const ks_sketches *s);

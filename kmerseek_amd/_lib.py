@@ -77,6 +77,7 @@ SIGNATURES = {
     "ks_sketch_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32, _parp, _pp]),
     "ks_sketch_queries_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32, _pp]),
     "ks_sketch_search_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32, _pp, _pp]),
+    "ks_sketch_search": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _pp, _pp]),
     "ks_sketches_has_postings": (C.c_int, [_vp]),
     "ks_sketches_n_seqs": (C.c_uint32, [_vp]),
     "ks_sketches_n_hashes": (C.c_uint64, [_vp]),

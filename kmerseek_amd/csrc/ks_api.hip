@@ -265,12 +265,8 @@ extern "C" int ks_search(ks_ctx *ctx, const ks_index *index, const ks_sketches *
 // brings the sketch's control block back together with the join's counts — two waits per step instead of three.  A batch whose
 // sketch has to be repeated (an economy that did not fit, dropped postings, a look-back that gave up: all rare) is simply
 // done again with the two plain calls.
-extern "C" int ks_sketch_search_device(ks_ctx *ctx, const ks_index *index, const uint8_t *d_residues,
-                                       const uint64_t *d_seq_offsets, uint32_t n_seqs, uint64_t n_residues,
-                                       uint32_t max_seq_len, ks_sketches **sketches_out, ks_hits **hits_out) {
-    return ks_guard(ctx, [&]() -> int {
-    if (!ctx) return KS_ERR_INVALID_ARG;
-    if (!index || !hits_out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+static int sketch_search_impl(ks_ctx *ctx, const ks_index *index, const uint8_t *d_residues, const uint64_t *d_seq_offsets, uint32_t n_seqs,
+                              uint64_t n_residues, uint32_t max_seq_len, ks_sketches **sketches_out, ks_hits **hits_out) {
     *hits_out = nullptr;
     if (sketches_out) *sketches_out = nullptr;
     const int fmt10 = (index->fp_layout && index->fp_shift == 32 - index->pbits) ? 1 : 0;
@@ -301,6 +297,34 @@ extern "C" int ks_sketch_search_device(ks_ctx *ctx, const ks_index *index, const
     *hits_out = H;
     if (sketches_out) *sketches_out = S; else ks_sketches_free(S);
     return KS_OK;
+}
+
+extern "C" int ks_sketch_search_device(ks_ctx *ctx, const ks_index *index, const uint8_t *d_residues,
+                                       const uint64_t *d_seq_offsets, uint32_t n_seqs, uint64_t n_residues,
+                                       uint32_t max_seq_len, ks_sketches **sketches_out, ks_hits **hits_out) {
+    return ks_guard(ctx, [&]() -> int {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (!index || !hits_out || (!d_seq_offsets) || (!d_residues && n_residues)) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    return sketch_search_impl(ctx, index, d_residues, d_seq_offsets, n_seqs, n_residues, max_seq_len, sketches_out, hits_out);
+    });
+}
+
+// ... and from host arrays (the batch is uploaded, its longest record is known from the offsets: the read-back is always folded)
+extern "C" int ks_sketch_search(ks_ctx *ctx, const ks_index *index, const uint8_t *residues, const uint64_t *seq_offsets,
+                                uint32_t n_seqs, ks_sketches **sketches_out, ks_hits **hits_out) {
+    return ks_guard(ctx, [&]() -> int {
+    if (!ctx) return KS_ERR_INVALID_ARG;
+    if (!index || !hits_out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
+    u8 *d_res = nullptr;
+    u64 *d_offs = nullptr;
+    u64 n_res = 0;
+    u32 max_len = 0;
+    int st = upload_batch(ctx, residues, seq_offsets, n_seqs, &d_res, &d_offs, &n_res, &max_len);
+    if (st == KS_OK) st = sketch_search_impl(ctx, index, d_res, d_offs, n_seqs, n_res, max_len, sketches_out, hits_out);
+    (void)hipStreamSynchronize(ctx->stream);
+    ks_pool_free(ctx, d_res);
+    ks_pool_free(ctx, d_offs);
+    return st;
     });
 }
 extern "C" uint64_t ks_hits_count(const ks_hits *h) { return h ? h->n_hits : 0; }

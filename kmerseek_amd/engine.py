@@ -234,6 +234,15 @@ class Context:
                                                     n_residues, max_seq_len, C.byref(sk) if want_sketches else None, C.byref(hits)))
         return (Sketches(self, sk) if want_sketches else None), Hits(self, hits)
 
+    def sketch_search(self, index: "Index", residues: np.ndarray, offsets: np.ndarray, want_sketches: bool = True):
+        """ks_sketch_search: the same from host arrays (upload, sketch, search).  Returns (Sketches or None, Hits)."""
+        residues = np.ascontiguousarray(residues, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        sk, hits = C.c_void_p(), C.c_void_p()
+        self._check(self._L.ks_sketch_search(self._h, index._h, _ptr(residues), _ptr(offsets), len(offsets) - 1,
+                                             C.byref(sk) if want_sketches else None, C.byref(hits)))
+        return (Sketches(self, sk) if want_sketches else None), Hits(self, hits)
+
     def fused_stats(self) -> Dict[str, int]:
         """ks_sketch_search_device calls on this context: with the sketch read-back deferred / repeated the plain way."""
         v = (C.c_uint64 * 2)()

@@ -525,6 +525,11 @@ def test_one_call_sketch_search_equals_the_two_calls(ctx, monkeypatch, k, scaled
     got = H.to_host()
     for g, w in zip(got, want_h):
         assert np.array_equal(g, w)
+    Qh, Hh = ctx.sketch_search(ix, q_res, q_off)   # ks_sketch_search: the same from host arrays
+    for g, w in zip(Qh.to_host(), want_s):
+        assert np.array_equal(g, w)
+    for g, w in zip(Hh.to_host(), want_h):
+        assert np.array_equal(g, w)
     if nt <= 6000:
         wq = oracle.sketch_batch(q_res, q_off, k, scaled, mol, n_threads=8)
         wt = oracle.sketch_batch(t_res, t_off, k, scaled, mol, n_threads=8)
