@@ -337,6 +337,17 @@ def run_queries_sharded(args, env, ks, synth, ksd):
             r["fused_scratch_bytes"] = pb * n_q_hashes  # postings for the join, written by the same launch; not in `achieved`
             r["posting_bytes"] = pb
             r["achieved_incl_fused_scratch"] = (b + pb * n_q_hashes) / avg_s / 1e9
+            # What this kernel actually runs against (informational; `bound` stays the contract's "hbm"): the vector ALU.  The
+            # hash alone is ~75 plain + 24 half-rate (32-bit multiply: aux.device.u64_gmul_per_s_measured) instructions per
+            # window at k = 10 (ISA of k_sketch_tiles<0, 0, 10>; profiles/README.md): 123 quad-cycles per 64 windows and SIMD.
+            if (k, scaled, mol) == (10, 1, "protein"):
+                props = torch.cuda.get_device_properties(env.dev)
+                simds, clk = props.multi_processor_count * 4, 2.4e9
+                floor_s = (q_windows / 64.0) * 123 * 4 / simds / clk
+                r["valu_model"] = {"hash_quad_cycles_per_64_windows": 123, "simds": simds, "clock_hz_assumed": clk,
+                                   "hash_only_floor_ms": floor_s * 1e3, "launch_over_hash_floor": avg_s / floor_s,
+                                   "note": "SQ counters: 1,871 vector instructions per wave of which ~216 are half-rate multiplies = 2,087 "
+                                           "quad-cycles per wave x 614 waves per SIMD = ~83 % of the launch time (profiles/r03_sq_counters.md)"}
         else:
             r["design_bytes_per_launch"] = b
             r["note"] = "scratch pass of the search: bytes it has to move by design, not SURVEY 8(d) algorithmic bytes"
