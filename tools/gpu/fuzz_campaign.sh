@@ -16,3 +16,5 @@ SEED=309 timeout -k 10 600 python tools/fuzz_parity.py --big --cases 20 --seed 3
 # big batches against an index in the fingerprint layout: 10-byte query postings at scaled = 1 (both fingerprint join kernels)
 SEED=313 KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=0 timeout -k 10 500 python tools/fuzz_parity.py --big --cases 12 --seed 313 > gpurun_out/r3_fz_big_fp_staged.log 2>&1; echo "big_fp_staged rc=$? $(tail -1 gpurun_out/r3_fz_big_fp_staged.log)"
 SEED=314 KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=1 timeout -k 10 500 python tools/fuzz_parity.py --big --cases 12 --seed 314 > gpurun_out/r3_fz_big_fp_sparse.log 2>&1; echo "big_fp_sparse rc=$? $(tail -1 gpurun_out/r3_fz_big_fp_sparse.log)"
+# ... and with the pair list forced into segments: the match sort's first level reads the segments in place (lists of >= 65,536 records)
+SEED=316 KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SEGS=1 timeout -k 10 500 python tools/fuzz_parity.py --big --cases 12 --seed 316 > gpurun_out/r3_fz_big_fp_segs.log 2>&1; echo "big_fp_segs rc=$? $(tail -1 gpurun_out/r3_fz_big_fp_segs.log)"
