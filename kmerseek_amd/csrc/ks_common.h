@@ -45,7 +45,7 @@ struct ks_copy_engine; // ks_copy.hip: pinned staging + host copy threads for pa
     X(STAGED_H2D) X(PLAIN_COPIES) X(PAIRS_LSD) X(MSD_LDS_CAP) X(SCAN_3PASS) X(INDEX_LSD) X(JOIN_FP) X(FP_COARSEN)        \
     X(PAIR_LIMIT) X(PBITS_MAX) X(UNPACKED_PAIRS) X(ONE_CURSOR) X(JOIN_SEGS) X(JOIN_SEG_CAP) X(JOIN_SPARSE) X(UNFUSED_ROWS) \
     X(NO_ROWS_HINT) X(ROWS_TICKET) X(FORCE_ROWS_TICKET_RETRY) X(FORCE_TICKET_RETRY) X(NO_PLAN) X(NO_COMPACT) X(SPAN)      \
-    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP) X(SYNC_API) X(POSTINGS12) X(NO_DEFER)
+    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP) X(SYNC_API) X(POSTINGS12) X(NO_DEFER) X(BUCKET) X(JOIN_SPLIT)
 enum ks_dbg_id {
 #define KS_DBG_ENUM(n) KS_DBG_##n,
     KS_DBG_LIST(KS_DBG_ENUM)
@@ -257,7 +257,7 @@ struct ks_index {
     int fp_shift;      // 32 - pbits (KS_DEBUG_FP_COARSEN adds to it: coarser fingerprints, more false candidates — tests)
     u32 max_abund; // largest of them: how many low bits of a packed match record the abundance needs
     u64 *d_dir;    // join-bucket directory: d_dir[b] = first posting whose join prefix is >= b (2^pbits + 1 entries)
-    int pbits;     // join prefix bits, a function of n_postings alone (ks_join_pbits)
+    int pbits;     // join prefix bits, a function of n_postings and the layout alone (ks_join_pbits)
 };
 
 struct ks_hits {
@@ -346,7 +346,7 @@ ks_fetch_seg ks_sketch_pending_seg(const ks_sketches *S);
 // the fetch segment of the one-launch scans' give-up flag (see ks_scan_status_check); false: nothing to fetch
 bool ks_scan_status_seg(ks_ctx *ctx, ks_fetch_seg *out);
 // bits of hash prefix the join against an index of n_postings uses (buckets of ~3k index postings, <= 16)
-int ks_join_pbits(const ks_ctx *ctx, u64 n_postings);
+int ks_join_pbits(const ks_ctx *ctx, u64 n_postings, u64 per_bucket);
 // multiplier of ks_join_prefix (ks_device.h) for a join on pbits prefix bits of hashes kept below max_hash
 u32 ks_join_prefix_mul(int pbits, u64 max_hash);
 int ks_kmerpos_tiles_launch(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n_seqs, u64 n_res, const ks_params *p, u32 *d_seq,

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_split_vals(const u64 *vals, u64 n, u32 
     if ((threadIdx.x & 63) == 0 && a > *max_abund) atomicMax(max_abund, a); // (plain read first: almost every wave's maximum is already covered)
 }
 
-int ks_join_pbits(const ks_ctx *ctx, u64 n_postings);
+int ks_join_pbits(const ks_ctx *ctx, u64 n_postings, u64 per_bucket);
 __global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int pbits, u32 pfxK, u64 *dir);
 __global__ __launch_bounds__(256) void k_index_finish(const u64 *keys, const u32 *tids, const u32 *abunds, const u64 *dir, u64 n, int pbits,
                                                       u32 pfxK, int fp_shift, u32 *fp, ks_post *post);
@@ -114,8 +114,20 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
         ix->d_keys = k0; k0 = nullptr;
     }
     {
-        // the join-bucket directory belongs to the index (its prefix width depends on the posting count alone)
-        ix->pbits = ks_join_pbits(ctx, n);
+        // The layout of the join first (it sizes the buckets).  Indexes are joined on 4-byte fingerprints (streamed; a directory
+        // over them in LDS instead of a binary search) + 16-byte postings (fetched per candidate match).  Medium and small hp
+        // indexes keep the sorted columns (k_join_buckets_keys): with a two-letter alphabet most queries match, several times
+        // (200k x 200k hp k = 24: 49 M matches from 11 M query hashes), and the confirmation fetches then cost more than the
+        // searches save (0.885 vs 0.845 ms there; protein / dayhoff: 100k x 100k k = 10 join 0.262 -> 0.194 ms, configs[1]
+        // 35 -> 29 us, configs[2] 56 -> 46 us).  KS_DEBUG_JOIN_FP = 1 / 0 forces either (big indexes: always fingerprints).
+        const bool big = (n >> (JN_FP_PBITS - 1)) > 3072; // >= 2^JN_FP_PBITS buckets of ~3k postings (> 50 M postings)
+        ix->fp_layout = big || t->params.moltype != KS_HP;
+        if (const char *f = ks_dbg(ctx, KS_DBG_JOIN_FP)) ix->fp_layout = atoi(f) != 0 || big;
+        // the join-bucket directory belongs to the index (its prefix width depends on the posting count alone): buckets of ~3k
+        // postings, one LDS stage.  (Buckets of ~768 for the key-column join: 200k x 200k hp — 49 M matches, a kernel that is the
+        // emission of its records — 0.79 -> 0.47 ms, but 50k x 50k hp k = 32 — 0.4 M matches — 0.135 -> 0.415 ms: how many
+        // workgroups a bucket deserves depends on the matches, which the search knows and the index does not: see `split` there.)
+        ix->pbits = ks_join_pbits(ctx, n, 3072);
         const u32 nb = 1u << ix->pbits;
         const u32 K = ks_join_prefix_mul(ix->pbits, ks_max_hash(t->params.scaled));
         IX_CHECK(ks_alloc(ctx, &ix->d_dir, (size_t)nb + 1));
@@ -123,13 +135,6 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
         hipLaunchKernelGGL(k_bucket_dir, dim3((nb + 256) / 256), dim3(256), 0, ctx->stream, (const u64 *)ix->d_keys, n, ix->pbits, K, ix->d_dir);
         ks_timer_end(ctx);
         IX_HIP(hipGetLastError());
-        // Indexes are joined on 4-byte fingerprints (streamed; a directory over them in LDS instead of a binary search) + 16-byte
-        // postings (fetched per candidate match).  Medium and small hp indexes keep the sorted columns (k_join_buckets_keys): with
-        // a two-letter alphabet most queries match, several times (200k x 200k hp k = 24: 49 M matches from 11 M query hashes), and
-        // the confirmation fetches then cost more than the searches save (0.885 vs 0.845 ms there; protein / dayhoff: 100k x 100k
-        // k = 10 join 0.262 -> 0.194 ms, configs[1] 35 -> 29 us, configs[2] 56 -> 46 us).  KS_DEBUG_JOIN_FP = 1 / 0 forces either.
-        ix->fp_layout = ix->pbits >= JN_FP_PBITS || t->params.moltype != KS_HP;
-        if (const char *f = ks_dbg(ctx, KS_DBG_JOIN_FP)) ix->fp_layout = atoi(f) != 0 || ix->pbits >= JN_FP_PBITS;
         if (ix->fp_layout) {
         IX_CHECK(ks_alloc(ctx, &ix->d_fp, (size_t)(n ? n : 1)));
         IX_CHECK(ks_alloc(ctx, &ix->d_post, (size_t)(n ? n : 1)));
@@ -211,13 +216,14 @@ static int bits_for(u32 n) { // bits needed to represent ids 0..n-1
     return b < 1 ? 1 : b;
 }
 
-int ks_join_pbits(const ks_ctx *ctx, u64 n_postings) { // buckets of ~3k index postings; the query side is partitioned on the same bits
+int ks_join_pbits(const ks_ctx *ctx, u64 n_postings, u64 per) { // buckets of ~`per` index postings; the query side is partitioned on the same bits
     // (8 bits by the sketch kernel + up to 9 by the bucket scatter; KS_DEBUG_PBITS_MAX is a tuning aid.  An index keeps the
     // width it was built with: ks_index::pbits)
     int cap = 16;
     if (const char *f = ks_dbg(ctx, KS_DBG_PBITS_MAX)) { const int v = atoi(f); cap = v < 1 ? 1 : (v > 17 ? 17 : v); }
     int pbits = 0;
-    while (pbits < cap && (n_postings >> pbits) > 3072) pbits++;
+    if (const char *f = ks_dbg(ctx, KS_DBG_BUCKET)) { const long v = atol(f); if (v >= 64) per = (u64)v; } // (tuning aid)
+    while (pbits < cap && (n_postings >> pbits) > per) pbits++;
     return pbits;
 }
 
@@ -258,7 +264,12 @@ __global__ __launch_bounds__(256) void k_bucket_dir(const u64 *keys, u64 n, int 
 // ---- the join of small and medium indexes (fewer than 2^JN_FP_PBITS buckets): full 64-bit keys staged in LDS, one cursor.
 // With few buckets there is little to gain from a narrower stream, and searches that match most of their queries
 // (all-vs-all) are better off without the confirmation fetches of the fingerprint kernel below.
+#ifndef JN_CAP_KEYS
 #define JN_CAP_KEYS 6144 // 48 KiB of LDS -> 3 workgroups (24 waves) per CU
+#endif
+#ifndef JK_WLIST
+#define JK_WLIST JN_WLIST // pairs a wave lists per round before it falls back to per-lane emission
+#endif
 // number of staged keys < h.  Branchless halving on the ACTUAL bucket size: the trip count ceil(log2 n) is uniform
 // across the workgroup, and the probe positions are multiples of n/2, n/4, ... rather than of powers of two —
 // power-of-two probe strides put every lane of a wave on ONE LDS bank (measured: 86 % of the LDS cycles of this
@@ -280,15 +291,27 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets_keys(const u64 *qke
                                                              const u32 *itids, const u32 *iabunds, const u64 *q_lo,
                                                              const u64 *q_hi, const u64 *dir_t, u64 *pair_keys,
                                                              u32 *pair_vals, u64 cap, unsigned long long *cursor,
-                                                             int tbits, int abits) {
+                                                             int tbits, int abits, u32 split) {
     __shared__ u64 lk[JN_CAP_KEYS];
-    __shared__ u32 wlist[JN_THREADS / 64][JN_WLIST]; // per-wave list of the round's pairs (query | index posting << 13)
+    __shared__ u32 wlist[JN_THREADS / 64][JK_WLIST]; // per-wave list of the round's pairs (query | index posting << 13)
     __shared__ u32 scan_smem[JN_THREADS / 64 + 1];
     __shared__ unsigned long long base_s;
     const u32 tid = threadIdx.x;
-    const u64 qs = q_lo[blockIdx.x], qe = q_hi[blockIdx.x]; // dense postings: q_hi = q_lo + 1 (a directory)
-    const u64 ts = dir_t[blockIdx.x], te = dir_t[blockIdx.x + 1];
+    // `split` workgroups share a bucket: each stages the bucket's keys and joins its slice of the bucket's query postings.  A
+    // match-dense search (all-vs-all over a two-letter alphabet: 4 matches per query posting) is the emission of its records,
+    // a chain of memory latencies per lane: more, shorter workgroups per bucket hide it (the host picks `split` from the
+    // matches of the context's previous search).
+    const u32 bucket = split > 1 ? blockIdx.x / split : blockIdx.x, part = split > 1 ? blockIdx.x % split : 0u;
+    u64 qs = q_lo[bucket], qe = q_hi[bucket]; // dense postings: q_hi = q_lo + 1 (a directory)
+    const u64 ts = dir_t[bucket], te = dir_t[bucket + 1];
     if (qs == qe || ts == te) return;
+    if (split > 1) {
+        const u64 per = (qe - qs + split - 1) / split;
+        const u64 a = qs + per * part;
+        qe = a + per < qe ? a + per : qe;
+        qs = a;
+        if (qs >= qe) return;
+    }
     for (u64 c0 = ts; c0 < te; c0 += JN_CAP_KEYS) {
         const u32 n = (u32)((te - c0) < JN_CAP_KEYS ? (te - c0) : JN_CAP_KEYS);
         // JN_FILLU loads of a thread are in flight before their LDS stores (a plain loop waits out one memory latency
@@ -344,7 +367,7 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets_keys(const u64 *qke
                 const u32 lane = tid & 63u, wave = tid >> 6;
                 const u32 wbase = __shfl(off, 0, 64);                           // first pair of this wave inside the round
                 const u32 wtotal = __shfl(off + mine, 63, 64) - wbase;          // pairs of this wave
-                if (wtotal <= JN_WLIST) { // uniform per wave
+                if (wtotal <= JK_WLIST) { // uniform per wave
                     u32 p = off - wbase;
                     while (hit) {
                         const int e = __builtin_ctz(hit);
@@ -379,12 +402,24 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets_keys(const u64 *qke
                         const u32 c = inf >> 16;
                         const u32 q = qids[q0 + (u64)e * JN_THREADS + tid];
                         const u64 j0 = c0 + (inf & 0xffffu);
-                        for (u32 j = 0; j < c; j++, slot++) {
-                            if (slot < cap) {
-                                const u64 ids = ((u64)q << tbits) | itids[j0 + j];
-                                if (pair_vals) { pair_keys[slot] = ids; pair_vals[slot] = iabunds[j0 + j]; }
-                                else pair_keys[slot] = (ids << abits) | iabunds[j0 + j];
+                        // (four postings of the run at a time: their id / abundance loads are in flight together — an
+                        // all-vs-all emits ~20 records per lane and round, and one memory latency per record was the kernel)
+                        for (u32 j = 0; j < c; j += 4) {
+                            u32 tt[4], aa[4];
+#pragma unroll
+                            for (u32 u = 0; u < 4; u++) {
+                                const bool on = j + u < c && slot + u < cap;
+                                tt[u] = on ? itids[j0 + j + u] : 0u;
+                                aa[u] = on ? iabunds[j0 + j + u] : 0u;
                             }
+#pragma unroll
+                            for (u32 u = 0; u < 4; u++)
+                                if (j + u < c && slot + u < cap) {
+                                    const u64 ids = ((u64)q << tbits) | tt[u];
+                                    if (pair_vals) { pair_keys[slot + u] = ids; pair_vals[slot + u] = aa[u]; }
+                                    else pair_keys[slot + u] = (ids << abits) | aa[u];
+                                }
+                            slot += (c - j) < 4u ? (c - j) : 4u;
                         }
                     }
                 }
@@ -1342,10 +1377,19 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                     hipLaunchKernelGGL(q_s ? k_join_buckets<1> : k_join_buckets<0>, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
                                        (const u32 *)qv, (const u32 *)ix->d_fp, (const ks_post *)ix->d_post, (const ks_bmeta *)ix->d_bmeta, q_lo,
                                        q_hi, dir_t, pk0, pv0, seg_cap, cursor, n_segs - 1, tbits, abits, ix->fp_shift);
-                else
-                    hipLaunchKernelGGL(k_join_buckets_keys, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
+                else {
+                    // workgroups per bucket: the matches per query posting of this context's previous search, when the buckets
+                    // hold enough query postings to share (KS_DEBUG_JOIN_SPLIT forces it)
+                    u32 split = 1;
+                    if (ctx->pair_cap_hint > n_q && n_q / n_buckets >= 1024) { // (n_q may still be the pending sketch's upper bound)
+                        const u64 dens2 = 2 * ctx->pair_cap_hint / n_q;
+                        split = dens2 >= 6 ? 4u : (dens2 >= 3 ? 2u : 1u); // 200k x 200k hp: 0.73 / 0.59 / 0.53 / 0.59 ms with 1 / 2 / 4 / 8
+                    }
+                    if (const char *f = ks_dbg(ctx, KS_DBG_JOIN_SPLIT)) { const int v = atoi(f); if (v >= 1 && v <= 16) split = (u32)v; }
+                    hipLaunchKernelGGL(k_join_buckets_keys, dim3(n_buckets * split), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
                                        (const u32 *)qv, (const u64 *)ix->d_keys, (const u32 *)ix->d_tids, (const u32 *)ix->d_abunds,
-                                       q_lo, q_hi, dir_t, pk0, pv0, seg_cap, cursor, tbits, abits);
+                                       q_lo, q_hi, dir_t, pk0, pv0, seg_cap, cursor, tbits, abits, split);
+                }
                 ks_timer_end(ctx);
                 SE_HIP(hipGetLastError());
                 // the segment counts (+ the flag word beside the first): one copy, strided when the list is segmented

@@ -1077,7 +1077,9 @@ def test_join_kernels_agree_on_heavily_repeated_hashes(ctx, monkeypatch):
     assert len(want[0]) > 300 * 7000
     T = ctx.sketch_batch(t_res, t_off, k, scaled, mol)
     Q = ctx.sketch_batch(q_res, q_off, k, scaled, mol)
-    for label, env in (("default", {}), ("key columns", {"KS_DEBUG_JOIN_FP": "0"}), ("fingerprints, staged index", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "0"}),
+    for label, env in (("default", {}), ("key columns", {"KS_DEBUG_JOIN_FP": "0"}),
+                       ("key columns, three workgroups per bucket", {"KS_DEBUG_JOIN_FP": "0", "KS_DEBUG_JOIN_SPLIT": "3"}),
+                       ("fingerprints, staged index", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "0"}),
                        ("fingerprints, query table", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "1"}),
                        ("fingerprints, query table, segments", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "1", "KS_DEBUG_JOIN_SEGS": "1"}),
                        ("fingerprints, staged index, segments, coarse", {"KS_DEBUG_JOIN_FP": "1", "KS_DEBUG_JOIN_SPARSE": "0", "KS_DEBUG_JOIN_SEGS": "1",

@@ -2,6 +2,7 @@ mkdir -p gpurun_out
 run() { name=$1; shift; env "$@" timeout -k 10 500 python tools/fuzz_parity.py --cases 350 --seed $SEED > gpurun_out/r3_fz_$name.log 2>&1; echo "$name rc=$? $(tail -1 gpurun_out/r3_fz_$name.log)"; }
 SEED=301 run default A=1
 SEED=315 run key_columns KS_DEBUG_JOIN_FP=0
+SEED=318 run key_columns_split KS_DEBUG_JOIN_FP=0 KS_DEBUG_JOIN_SPLIT=3
 SEED=302 run fp_staged KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=0
 SEED=303 run fp_sparse KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=1
 SEED=304 run fp_sparse_segs_coarse KS_DEBUG_JOIN_FP=1 KS_DEBUG_JOIN_SPARSE=1 KS_DEBUG_JOIN_SEGS=1 KS_DEBUG_FP_COARSEN=18
