@@ -45,7 +45,7 @@ struct ks_copy_engine; // ks_copy.hip: pinned staging + host copy threads for pa
     X(STAGED_H2D) X(PLAIN_COPIES) X(PAIRS_LSD) X(MSD_LDS_CAP) X(SCAN_3PASS) X(INDEX_LSD) X(JOIN_FP) X(FP_COARSEN)        \
     X(PAIR_LIMIT) X(PBITS_MAX) X(UNPACKED_PAIRS) X(ONE_CURSOR) X(JOIN_SEGS) X(JOIN_SEG_CAP) X(JOIN_SPARSE) X(UNFUSED_ROWS) \
     X(NO_ROWS_HINT) X(ROWS_TICKET) X(FORCE_ROWS_TICKET_RETRY) X(FORCE_TICKET_RETRY) X(NO_PLAN) X(NO_COMPACT) X(SPAN)      \
-    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP) X(SYNC_API) X(POSTINGS12) X(NO_DEFER) X(BUCKET) X(JOIN_SPLIT)
+    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP) X(SYNC_API) X(POSTINGS12) X(NO_DEFER) X(BUCKET) X(JOIN_SPLIT) X(SUBSHIFT)
 enum ks_dbg_id {
 #define KS_DBG_ENUM(n) KS_DBG_##n,
     KS_DBG_LIST(KS_DBG_ENUM)

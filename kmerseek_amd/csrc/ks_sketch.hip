@@ -1883,7 +1883,14 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             S->part_regions = 1u << dbits;
             // one sub-region per XCD when a second partition pass follows (its tiles are per-segment anyway); when the
             // regions ARE the join buckets (<= 8 prefix bits) they must stay contiguous
-            S->part_sub_shift = part_pbits > 8 ? 3u : 0u;
+            // (... as many as leave a sub-region >= 64k postings: the bucket scatter works on tiles of 8,192 postings per sub-region, and
+            // a 125k-query shard of the 1M workload cut 2,048 ways fills 2.2 of them — 0.25 ms against 0.17 with 512 sub-regions;
+            // 10k queries: 44 -> 22 us with 256 — while the 1M batch wants all 2,048: fewer posting cursors cost its sketch kernel
+            // 2.49 -> 2.61 ms)
+            S->part_sub_shift = 0u;
+            if (part_pbits > 8)
+                while (S->part_sub_shift < 3u && (S->n_windows / p->scaled) >> (8u + S->part_sub_shift + 1u) >= 65536u) S->part_sub_shift++;
+            if (const char *f = ks_dbg(ctx, KS_DBG_SUBSHIFT)) { const int v = atoi(f); if (part_pbits > 8 && v >= 0 && v <= 3) S->part_sub_shift = (u32)v; }
             const u32 n_segs = S->part_regions << S->part_sub_shift;
             const u64 per = S->n_windows / p->scaled / n_segs + 1; // FracMinHash keeps ~1/scaled of the windows
             u64 cap = per + per / 4 + 8192;                 // uniform hashes fill regions evenly; skew -> fallback
