@@ -64,11 +64,27 @@ def parse_args():
 
 
 def relaunch_distributed(args):
-    """`python bench.py --gpus N` without a launcher: start the ranks as a child job (never exec)."""
+    """`python bench.py --gpus N` without a launcher: start the ranks as a child job (never exec) and return its exit code.
+    The launcher's stderr is passed through line by line and its tail is shown again when the job failed."""
+    import collections
+    import threading
     port = 29500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd)
+    child = subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True, errors="replace")
+    tail = collections.deque(maxlen=40)
+
+    def pump():
+        for line in child.stderr:
+            tail.append(line)
+            sys.stderr.write(line)
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    rc = child.wait()
+    t.join(timeout=5)
+    if rc != 0:
+        sys.stderr.write(f"[bench] the {args.gpus}-rank job failed (exit code {rc}); last lines of the launcher's stderr:\n" + "".join(tail))
+    return rc
 
 
 class Env:
@@ -89,16 +105,39 @@ class Env:
         self.dev_index = 0 if self.rehearse else local_rank
         torch.cuda.set_device(self.dev_index)
         self.dev = torch.device("cuda", self.dev_index)
+        # one HIP stream for everything this process queues: torch's current stream for the whole run, and the stream the
+        # library's context launches on (ks.Context(stream=...)) — torch ops on views of library-owned arrays, the library's
+        # kernels and the collectives torch.distributed orders against the current stream are all in one queue order
+        self.stream = torch.cuda.Stream(self.dev)
+        torch.cuda.set_stream(self.stream)
         self.cdev = torch.device("cpu") if self.rehearse else self.dev  # where collective buffers live
         self.backend = None
+        self.step_ms, self.tail_ms = [], 0.0
         if self.world > 1:
+            # Fail fast and say why: a rank that does not come up must not leave the others in the backend's default
+            # 10-minute wait (the driver's limit for the whole bench is of that order: a hang would look like a slow run).
+            from datetime import timedelta
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             self.backend = "gloo" if self.rehearse else "nccl"
-            if self.rehearse:
-                dist.init_process_group("gloo")
-            else:
-                dist.init_process_group("nccl", device_id=self.dev)
-            dist.barrier()
+            tmo = timedelta(seconds=int(os.environ.get("KS_BENCH_PG_TIMEOUT_S", "120")))
+            what = "init_process_group"
+            try:
+                if self.rehearse:
+                    dist.init_process_group("gloo", timeout=tmo)
+                else:
+                    dist.init_process_group("nccl", device_id=self.dev, timeout=tmo)
+                what = "first collective (all_reduce of one word per rank)"
+                t = torch.ones(1, dtype=torch.int64, device=self.cdev)
+                dist.all_reduce(t)
+                torch.cuda.synchronize(self.dev)
+                if int(t[0]) != self.world:
+                    raise RuntimeError(f"all_reduce over {self.world} ranks returned {int(t[0])}")
+            except BaseException as e:  # (a plain exit of this child process with a non-zero code; never a re-exec)
+                sys.stderr.write(f"[bench rank {self.rank}/{self.world} device cuda:{self.dev_index} backend {self.backend} "
+                                 f"MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}] {what} failed within "
+                                 f"{tmo.total_seconds():.0f} s: {type(e).__name__}: {e}\n")
+                sys.stderr.flush()
+                os._exit(3)
 
     def barrier(self):
         if self.world > 1:
@@ -107,21 +146,40 @@ class Env:
 
     def timed(self, fn, steps, finalize=None):
         """EXACTLY `steps` calls of fn between barrier + synchronize on both sides; max over ranks.  `finalize(out)` runs
-        inside the timed region after the last call (a pipelined step completes its last exchange there)."""
+        inside the timed region after the last call (a pipelined step completes its last exchange there).
+        `self.step_ms` = this rank's host wall time of every call (a step returns after its last host wait, so these are
+        step times, not enqueue times; one perf_counter read per step is the only thing added to the region)."""
+        marks = [0.0] * (steps + 2)
         self.barrier()
         t0 = time.perf_counter()
+        marks[0] = t0
         out = None
-        for _ in range(steps):
+        for i in range(steps):
             out = fn()
+            marks[i + 1] = time.perf_counter()
         if finalize is not None:
             out = finalize(out)
         self.barrier()
-        el = time.perf_counter() - t0
+        marks[steps + 1] = time.perf_counter()
+        el = marks[steps + 1] - t0
+        self.step_ms = [(marks[i + 1] - marks[i]) * 1e3 for i in range(steps)]
+        self.tail_ms = (marks[steps + 1] - marks[steps]) * 1e3  # finalize + closing barrier / synchronize
         if self.world > 1:
             t = self.torch.tensor([el], dtype=self.torch.float64, device=self.cdev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             el = float(t[0])
         return el, out
+
+    def step_times(self):
+        """min / median / max of the per-step wall times of the last timed region (the median beside the mean)."""
+        v = sorted(self.step_ms)
+        if not v:
+            return None
+        n = len(v)
+        med = v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+        return {"min": v[0], "median": med, "max": v[-1], "first": self.step_ms[0], "last": self.step_ms[-1],
+                "finalize_and_barrier_ms": self.tail_ms, "n": n,
+                "all": [round(x, 4) for x in self.step_ms]}
 
     def sum_ints(self, vals):
         t = self.torch.tensor(list(vals), dtype=self.torch.int64, device=self.cdev)
@@ -132,6 +190,68 @@ class Env:
     def close(self):
         if self.world > 1:
             self.dist.destroy_process_group()
+
+
+def counters(ctx):
+    """The library's own record of what it had to repeat or allocate (include/kmerseek_amd.h: ks_ctx_pool_stats,
+    ks_ctx_fused_stats, ks_ctx_search_stats, ks_ctx_sketch_stats)."""
+    return {"pool": ctx.pool_stats(), "fused": ctx.fused_stats(), "search": ctx.search_stats(), "sketch": ctx.sketch_stats()}
+
+
+def counters_delta(before, after):
+    """What moved inside a timed region: hipMalloc calls of the pool, pool growth, repeats; the steady state is all zeros
+    (except `fused.deferred`, which counts the one-call steps that did NOT need a repeat)."""
+    d = {"pool_mallocs": after["pool"]["mallocs"] - before["pool"]["mallocs"],
+         "pool_bytes_held_before": before["pool"]["bytes_held"], "pool_bytes_held_after": after["pool"]["bytes_held"],
+         "pool_blocks_before": before["pool"]["blocks"], "pool_blocks_after": after["pool"]["blocks"]}
+    for grp in ("fused", "search", "sketch"):
+        for k_, v in after[grp].items():
+            d[f"{grp}.{k_}"] = v - before[grp][k_] if k_ != "uses_ticket" else v
+    return d
+
+
+def self_check(env, ksd, ctx, index, d_res, d_off, n, n_res, max_len):
+    """Untimed, after the timed region: the entry the steps went through (ks_sketch_search_device) against the two plain calls
+    (ks_sketch_queries_device + ks_search) on the same batch — same sketches, same rows, and the rows' intersect column sums
+    to the matched posting pairs.  A bench line whose rows are wrong is not evidence (tests/test_gpu_fullsize.py holds both
+    against the oracle at this size)."""
+    torch = env.torch
+    Q2 = ctx.sketch_queries_device(index, d_res, d_off, n, n_res, max_seq_len=max_len)
+    H2 = ctx.search(index, Q2)
+    Q1, H1 = ctx.sketch_search_device(index, d_res, d_off, n, n_res, max_seq_len=max_len)
+    out = {"n_hashes": [Q1.n_hashes, Q2.n_hashes], "hits": [H1.count, H2.count],
+           "matched_posting_pairs": [H1.n_pair_instances, H2.n_pair_instances]}
+    ok = out["n_hashes"][0] == out["n_hashes"][1] and out["hits"][0] == out["hits"][1]
+    if ok:
+        r1, r2 = ksd._hit_columns_as_torch(H1, H1.count, env.dev), ksd._hit_columns_as_torch(H2, H2.count, env.dev)
+        s1, s2 = ksd.sketch_columns_as_torch(Q1, env.dev), ksd.sketch_columns_as_torch(Q2, env.dev)
+        out["rows_equal"] = all(bool(torch.equal(a, b)) for a, b in zip(r1, r2))
+        out["sketches_equal"] = all(bool(torch.equal(a, b)) for a, b in zip(s1, s2))
+        out["sum_intersect"] = int(r1[2].sum()) if H1.count else 0
+        key = (r1[0].to(torch.int64) << 32) | r1[1].to(torch.int64)
+        out["rows_strictly_ordered_by_qid_tid"] = bool((key[1:] > key[:-1]).all()) if key.numel() > 1 else True
+        ok = (out["rows_equal"] and out["sketches_equal"] and out["sum_intersect"] == out["matched_posting_pairs"][0]
+              and out["rows_strictly_ordered_by_qid_tid"])
+        del r1, r2, s1, s2, key
+    out["ok"] = bool(ok)
+    H1.free(); Q1.free(); H2.free(); Q2.free()
+    if not ok:
+        raise AssertionError(f"bench self-check failed: one-call entry != two-call result: {out}")
+    return out
+
+
+def sharded_equals_unsharded(env, ksd, ctx, gathered, unsharded_hits):
+    """SURVEY 8(e) correctness gate, untimed: the N-rank result (gathered columns in global (qid, tid) order, identical on
+    every rank) against rank 0's own unsharded search of the whole job, bit for bit."""
+    torch = env.torch
+    want = ksd._hit_columns_as_torch(unsharded_hits, unsharded_hits.count, env.dev)
+    got = [c.to(env.dev) for c in gathered]
+    same = all(g.numel() == w.numel() and bool(torch.equal(g, w)) for g, w in zip(got, want))
+    out = {"rows_gathered": int(got[0].numel()), "rows_unsharded": int(want[0].numel()), "equal": bool(same)}
+    del want, got
+    if not same and (env.rehearse or os.environ.get("KS_BENCH_STRICT") == "1"):
+        raise AssertionError(f"sharded result != unsharded result: {out}")
+    return out
 
 
 def device_shard(env, res, off, s0, s1):
@@ -179,7 +299,9 @@ def run_queries_sharded(args, env, ks, synth, ksd):
         s0, s1 = ksd.shard_by_residues(off_host, world)[rank]
         q_res, q_off, n_q_res = device_shard(env, qa_res, qa_off, s0, s1)
         n_q = s1 - s0
-        del qa_res, qa_off
+        q_base = s0
+        if world == 1 or rank != 0:
+            del qa_res, qa_off  # (rank 0 of an N-rank job keeps the whole batch for the sharded == unsharded check)
     else:
         if rank != 0:
             t_res_h = t_res.cpu().numpy()
@@ -227,7 +349,10 @@ def run_queries_sharded(args, env, ks, synth, ksd):
     # every launch would add ~20 us of idle queue per launch to each step)
     ctx.timing_reset()
     ctx.timing_enable(2)
+    c_before = counters(ctx)
     elapsed, stats = env.timed(step, args.steps)
+    c_after = counters(ctx)
+    step_times = env.step_times()
     ctx.timing_enable(False)
     timing = ctx.timing()
     # untimed extra pass with every launch bracketed, for the complete per-kernel table
@@ -237,6 +362,20 @@ def run_queries_sharded(args, env, ks, synth, ksd):
         step()
     ctx.timing_enable(False)
     timing_all = {k_: (n_ / 2, ms_ / 2) for k_, (n_, ms_) in ctx.timing().items()}
+    check = self_check(env, ksd, ctx, index, q_res.data_ptr(), q_off.data_ptr(), n_q, n_q_res, q_maxlen)
+    gate = None
+    if world > 1 and strong:
+        # every rank's hit list of its query shard, all-gathered (qid ranges ascend with the rank: the concatenation IS the
+        # global order) == rank 0 searching all the queries by itself
+        Q, H = ctx.sketch_search_device(index, q_res.data_ptr(), q_off.data_ptr(), n_q, n_q_res, max_seq_len=q_maxlen)
+        got = ksd.all_gather_hits_device(H, qid_base=q_base, device=env.cdev, sharded="queries", id_counts=(args.queries, args.targets))
+        H.free(); Q.free()
+        if rank == 0:
+            Qa, Ha = ctx.sketch_search_device(index, qa_res.data_ptr(), qa_off.data_ptr(), args.queries, int(qa_res.numel()))
+            gate = sharded_equals_unsharded(env, ksd, ctx, got, Ha)
+            Ha.free(); Qa.free()
+            del qa_res, qa_off
+        del got
 
     # ---- SURVEY §8(d) side lines (rank 0, after the timed region; none of them is `value`)
     aux = None
@@ -378,6 +517,8 @@ def run_queries_sharded(args, env, ks, synth, ksd):
     result = {
         "metric": "k-mers hashed+matched/sec", "value": value, "unit": "k-mers/s", "n_gpus": args.gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "step_ms": step_times, "timed_region_counters": counters_delta(c_before, c_after), "self_check": check,
+        "sharded_equals_unsharded": gate,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u64",
         "data": "synthetic",
         "config": {"workload": f"{args.queries // 1000}k query proteins vs {args.targets // 1000}k-protein index, {mol} k={k} "
@@ -597,7 +738,12 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
     for _ in range(max(args.warmup, 1)):
         stats, rows = step()
     stats, rows = drain((stats, rows))
+    rows = None  # (the warm-up's last hit list must not stay alive beside the three the timed loop keeps: one more list than the
+                 # warm-up ever held at once = three fresh blocks = three hipMalloc calls inside the timed region, ~1.3 ms of one step)
+    c_before = counters(ctx)
     elapsed, (stats, rows) = env.timed(step, args.steps, finalize=drain)
+    c_after = counters(ctx)
+    step_times = env.step_times()
     # per-kernel table + roofline of this config (untimed pass with every launch bracketed by HIP events on the launch stream)
     n_t_postings = index.n_postings
     ctx.timing_reset()
@@ -607,6 +753,20 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
     drain((None, None))
     ctx.timing_enable(False)
     timing_all = {k_: (n_ / 2, ms_ / 2) for k_, (n_, ms_) in ctx.timing().items()}
+    check = self_check(env, ksd, ctx, index, p_res.data_ptr(), p_off.data_ptr(), n_prot, n_res, q_maxlen)
+    gate = None
+    if world > 1:
+        # the per-shard hit lists gathered and merged into global (qid, tid) order == rank 0's unsharded all-vs-all
+        Q, H = ctx.sketch_search_device(index, p_res.data_ptr(), p_off.data_ptr(), n_prot, n_res, max_seq_len=q_maxlen)
+        got = ksd.all_gather_hits_device(H, tid_base=s0, device=env.cdev, sharded="index", order="qid", id_counts=(n_prot, n_prot))
+        H.free(); Q.free()
+        if rank == 0:
+            Ta = ctx.sketch_batch_device(p_res.data_ptr(), p_off.data_ptr(), n_prot, n_res, k, scaled, mol)
+            ixa = ctx.index_build(Ta)
+            Qa, Ha = ctx.sketch_search_device(ixa, p_res.data_ptr(), p_off.data_ptr(), n_prot, n_res, max_seq_len=q_maxlen)
+            gate = sharded_equals_unsharded(env, ksd, ctx, got, Ha)
+            Ha.free(); Qa.free(); ixa.free(); Ta.free()
+        del got
     # the gathered list is complete and holds every (qid, tid) pair once: checked once, outside the timed region, by sorting
     key = torch.sort(rows[0].to(torch.int64) << 32 | rows[1].to(torch.int64)).values
     ordered = bool((key[1:] > key[:-1]).all()) if key.numel() > 1 else True
@@ -652,6 +812,8 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
         "kernels": {name: {"launches_per_step": n, "ms_per_step": ms} for name, (n, ms) in timing_all.items()},
         "metric": "k-mers hashed+matched/sec", "value": q_windows * args.steps / elapsed, "unit": "k-mers/s",
         "n_gpus": args.gpus, "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3,
+        "step_ms": step_times, "timed_region_counters": counters_delta(c_before, c_after), "self_check": check,
+        "sharded_equals_unsharded": gate,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"all-vs-all containment, {n_prot // 1000}k proteins, {mol} k={k} scaled={scaled} "
                                f"(BASELINE configs[4]: index sharded by target id, per-shard hit lists all-gathered)",

@@ -85,7 +85,9 @@ int ks_moltype_from_string(const char *name, uint32_t *moltype_out);
 uint64_t ks_max_hash(uint32_t scaled);
 
 /* hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
- * to let the context create its own non-blocking stream. */
+ * to let the context create its own non-blocking stream.  The device's default (null) stream cannot be named by NULL here:
+ * pass hipStreamLegacy ((hipStream_t)1) for it — kmerseek_amd/engine.py does that for a caller that hands over the 0
+ * torch reports for its default stream. */
 int ks_ctx_create(int device, void *hip_stream, ks_ctx **out);
 void ks_ctx_destroy(ks_ctx *ctx);
 const char *ks_last_error(const ks_ctx *ctx);
@@ -280,8 +282,10 @@ int ks_hits_unpack64_device(ks_ctx *ctx, const uint64_t *d_packed, uint64_t n, i
 /* Index-sharded exchange, global (qid, tid) order: the gathered rows are n_blocks rank blocks (block r = block_rows[r] rows,
  * host array), each ordered by (qid, tid), the ranks' target ranges ascending.  One counting merge (per (query, rank) run
  * lengths by binary search -> exclusive scan -> one move) writes them ordered by (qid, tid) into the caller-owned output
- * columns (device, sum(block_rows) entries; must not alias the inputs).  qid values must be < n_queries.  Asynchronous on
- * ctx's stream.  (Rows per query as branchwater manysearch lists them: src/python/kmerseek/search.py:125-141.) */
+ * columns (device, sum(block_rows) entries; must not alias the inputs).  qid values must be < n_queries: a row that is not
+ * has no place in the merged order, and the call fails with KS_ERR_INVALID_ARG (outputs then incomplete) instead of leaving a
+ * gap.  Returns after the move has run (one wait on ctx's stream: the count of such rows comes back with it).
+ * (Rows per query as branchwater manysearch lists them: src/python/kmerseek/search.py:125-141.) */
 int ks_hits_merge_by_qid_device(ks_ctx *ctx, const uint32_t *d_qid, const uint32_t *d_tid, const uint32_t *d_intersect,
                                 const uint64_t *d_n_weighted, const uint64_t *block_rows, uint32_t n_blocks, uint32_t n_queries,
                                 uint32_t *d_out_qid, uint32_t *d_out_tid, uint32_t *d_out_intersect, uint64_t *d_out_n_weighted);

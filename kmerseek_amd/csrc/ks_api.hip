@@ -382,7 +382,7 @@ extern "C" int ks_hits_copy_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t qi
 // ids in global numbering.  A row whose intersect or n_weighted does not fit v bits carries all-ones in both value fields and
 // its true values go to a short escape list (row index, intersect, n_weighted), gathered beside the words.
 __global__ __launch_bounds__(256) void k_hits_pack64(const u32 *qid, const u32 *tid, const u32 *isect, const u64 *nw, u64 n, u32 qid_base,
-                                                     u32 tid_base, int tbits, int vbits, u64 *packed, u32 *esc_row, u32 *esc_isect,
+                                                     u32 tid_base, int qbits, int tbits, int vbits, u64 *packed, u32 *esc_row, u32 *esc_isect,
                                                      u64 *esc_nw, u32 *n_esc, u32 esc_cap) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -396,7 +396,9 @@ __global__ __launch_bounds__(256) void k_hits_pack64(const u32 *qid, const u32 *
     const u64 q = (u64)qid[i] + qid_base, t = (u64)tid[i] + tid_base;
     // an id that does not fit its field (id_counts smaller than the real global range) would spill into its neighbour:
     // the escape count is pushed beyond any capacity instead, so every rank takes the unpacked exchange
-    if ((q >> (64 - tbits - 2 * vbits)) != 0 || (t >> tbits) != 0) atomicOr(n_esc, 0x80000000u);
+    // (tested against qbits itself: 64 - tbits - 2v is one bit wider when 64 - qbits - tbits is odd, and the receiving side
+    // masks with qbits)
+    if ((q >> qbits) != 0 || (t >> tbits) != 0) atomicOr(n_esc, 0x80000000u);
     packed[i] = (((q << tbits) | t) << (2 * vbits)) | (a << vbits) | b;
 }
 
@@ -416,7 +418,7 @@ extern "C" int ks_hits_pack64_to_device(ks_ctx *ctx, const ks_hits *h, uint32_t 
     if (n >= 0xffffffffULL) return ks_fail(ctx, KS_ERR_CAPACITY, "pack64: %llu rows (escape rows are 32-bit indices)", (unsigned long long)n);
     if (!d_packed || (esc_cap && (!d_esc_row || !d_esc_intersect || !d_esc_n_weighted))) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     KS_LAUNCH(ctx, "hits_pack", k_hits_pack64, (u32)((n + 255) / 256), 256, (const u32 *)h->d_qid, (const u32 *)h->d_tid, (const u32 *)h->d_isect,
-              (const u64 *)h->d_nw, n, qid_base, tid_base, tbits, (64 - qbits - tbits) / 2, d_packed, d_esc_row, d_esc_intersect, d_esc_n_weighted,
+              (const u64 *)h->d_nw, n, qid_base, tid_base, qbits, tbits, (64 - qbits - tbits) / 2, d_packed, d_esc_row, d_esc_intersect, d_esc_n_weighted,
               d_n_esc, esc_cap);
     return KS_OK;
     });
@@ -482,13 +484,14 @@ __global__ __launch_bounds__(256) void k_hm_runs(const u32 *first, u32 W, u32 nq
     run[i] = first[at + 1] - first[at];
 }
 __global__ __launch_bounds__(256) void k_hm_move(const u32 *qid, const u32 *tid, const u32 *isect, const u64 *nw, hm_blocks B, u32 nq,
-                                                 const u32 *first, const u32 *start, u32 *o_qid, u32 *o_tid, u32 *o_isect, u64 *o_nw) {
+                                                 const u32 *first, const u32 *start, u32 *o_qid, u32 *o_tid, u32 *o_isect, u64 *o_nw,
+                                                 u32 *n_dropped) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B.base[B.n]) return;
     u32 r = 0;
     while (r + 1 < B.n && i >= B.base[r + 1]) r++; // (W <= 64 blocks)
     const u32 q = qid[i];
-    if (q >= nq) return; // (an id beyond the declared range: dropped rather than written out of bounds; the caller checks counts)
+    if (q >= nq) { atomicAdd(n_dropped, 1u); return; } // (an id beyond the declared range: not written out of bounds, but counted — the call fails)
     const u64 pos = (u64)start[(u64)q * B.n + r] + ((i - B.base[r]) - first[(u64)r * ((u64)nq + 1) + q]);
     o_qid[pos] = q; o_tid[pos] = tid[i]; o_isect[pos] = isect[i]; o_nw[pos] = nw[i];
 }
@@ -511,7 +514,9 @@ extern "C" int ks_hits_merge_by_qid_device(ks_ctx *ctx, const uint32_t *d_qid, c
     u32 *first = nullptr, *run = nullptr;
     const u64 n_first = ((u64)n_queries + 1) * n_blocks, n_run = (u64)n_queries * n_blocks;
     int st = ks_alloc(ctx, &first, (size_t)n_first);
-    if (st == KS_OK) st = ks_alloc(ctx, &run, (size_t)n_run + 1);
+    if (st == KS_OK) st = ks_alloc(ctx, &run, (size_t)n_run + 2); // (+ the scan's total, + the count of rows with an id out of range)
+    u32 *const n_dropped = run ? run + n_run + 1 : nullptr;
+    if (st == KS_OK && hipMemsetAsync(n_dropped, 0, sizeof(u32), ctx->stream) != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "merge: memset failed");
     if (st == KS_OK) {
         ks_timer_begin(ctx, "hits_merge");
         hipLaunchKernelGGL(k_hm_starts, dim3((u32)((n_first + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)d_qid, B, n_queries, first);
@@ -523,9 +528,15 @@ extern "C" int ks_hits_merge_by_qid_device(ks_ctx *ctx, const uint32_t *d_qid, c
         ks_timer_begin(ctx, "hits_merge");
         hipLaunchKernelGGL(k_hm_move, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u32 *)d_qid, (const u32 *)d_tid,
                            (const u32 *)d_intersect, (const u64 *)d_n_weighted, B, n_queries, (const u32 *)first, (const u32 *)run, d_out_qid,
-                           d_out_tid, d_out_intersect, (u64 *)d_out_n_weighted);
+                           d_out_tid, d_out_intersect, (u64 *)d_out_n_weighted, n_dropped);
         ks_timer_end(ctx);
         if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "merge launch failed");
+    }
+    if (st == KS_OK) { // a row whose query id lies beyond n_queries has no place in the merged order: the outputs would hold a gap
+        const ks_fetch_seg f = ks_fetch_words(n_dropped, ctx->h_pin, 1);
+        st = ks_stream_wait_fetch(ctx, &f, 1);
+        if (st == KS_OK && *(const u32 *)ctx->h_pin != 0)
+            st = ks_fail(ctx, KS_ERR_INVALID_ARG, "merge: %u rows carry a query id >= n_queries = %u", *(const u32 *)ctx->h_pin, n_queries);
     }
     // (the scratch blocks go back to the pool in stream order: the next allocation on this context's stream comes behind the kernels)
     ks_pool_free(ctx, first); ks_pool_free(ctx, run);

@@ -23,7 +23,7 @@ typedef int64_t i64;
 
 #define KS_WAVE 64
 
-// ---- device memory pool: grow-only, best-fit reuse, so steady-state batches never hipMalloc ----
+// ---- device memory pool: grow-only, size classes with exact-fit reuse (ks_ctx.hip), so steady-state batches never hipMalloc ----
 struct ks_pool_block {
     void *ptr;
     size_t size;

@@ -175,8 +175,10 @@ extern "C" int ks_ctx_create(int device, void *hip_stream, ks_ctx **out) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
         ctx->own_stream = true;
     }
-    if (hipHostMalloc((void **)&ctx->h_pin, KS_PIN_WORDS * sizeof(u64)) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
-    if (hipHostMalloc((void **)&ctx->h_flag, 64) != hipSuccess) { (void)hipGetLastError(); ctx->h_flag = nullptr; } // (ks_stream_wait falls back to the API)
+    // (coherent, explicitly: the host SPINS on words the device writes while its kernel is still in the queue — with
+    // HIP_HOST_COHERENT=0 in the environment the default flags would give non-coherent memory, visible only after a synchronisation)
+    if (hipHostMalloc((void **)&ctx->h_pin, KS_PIN_WORDS * sizeof(u64), hipHostMallocCoherent) != hipSuccess) { delete ctx; return KS_ERR_HIP; }
+    if (hipHostMalloc((void **)&ctx->h_flag, 64, hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); ctx->h_flag = nullptr; } // (ks_stream_wait falls back to the API)
     else *ctx->h_flag = 0;
     if (hipMalloc((void **)&ctx->d_lut, 3 * 256) != hipSuccess) { delete ctx; return KS_ERR_OOM; }
     u8 lut[768];
@@ -370,17 +372,27 @@ static int stream_wait_poll(ks_ctx *ctx, unsigned long long seq) {
 }
 
 // ---- pool ---------------------------------------------------------------------------------
+// Size classes, exact fit.  A request is rounded up to its class (four classes per octave: 1.25 / 1.5 / 1.75 / 2 x 2^e, at most
+// 25 % over the request, 256-byte steps below 4 KB) and only a free block of exactly that class serves it.  So the number of
+// blocks a class ever holds is the largest number of them alive at once: a caller that keeps the last two or three results
+// alive while the next step runs (views of a hit list, a pipelined exchange) reaches its steady state after as many steps
+// and never calls hipMalloc — which synchronises the device — again.  (Round 3's rule let a request take any free block up
+// to twice its size: small requests took the big blocks of results whose release was deferred, the big requests then found
+// nothing and the pool kept growing — 5 hipMalloc calls inside a 20-step timed region of the configs[4] bench line.)
+static size_t pool_class(size_t bytes) {
+    if (bytes <= 4096) return (bytes + 255) & ~(size_t)255;
+    const int e = 63 - __builtin_clzll((unsigned long long)(bytes - 1)); // bytes in (2^e, 2^(e+1)]
+    const size_t step = (size_t)1 << (e - 2);
+    return (bytes + step - 1) & ~(step - 1);
+}
+
 void *ks_pool_alloc(ks_ctx *ctx, size_t bytes) {
     if (bytes == 0) bytes = 256;
-    bytes = (bytes + 255) & ~(size_t)255;
-    int best = -1;
+    const size_t want = pool_class(bytes);
     for (size_t i = 0; i < ctx->pool.size(); i++) {
         auto &b = ctx->pool[i];
-        if (!b.in_use && b.size >= bytes && b.size <= bytes * 2 + (1u << 20))
-            if (best < 0 || b.size < ctx->pool[best].size) best = (int)i;
+        if (!b.in_use && b.size == want) { b.in_use = true; return b.ptr; }
     }
-    if (best >= 0) { ctx->pool[best].in_use = true; return ctx->pool[best].ptr; }
-    size_t want = bytes < (1u << 20) ? bytes : ((bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1));
     if (ctx->pool_cap) { // KS_DEBUG_POOL_CAP (tests): behave like a device that is full
         size_t held = 0;
         for (auto &b : ctx->pool) held += b.size;
@@ -391,8 +403,16 @@ void *ks_pool_alloc(ks_ctx *ctx, size_t bytes) {
     }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) { // give cached blocks back and retry once
-        ks_pool_trim(ctx);
+    if (e != hipSuccess) {
+        // the device is full: any free block that is large enough will do (smallest first) ...
+        (void)hipGetLastError();
+        int best = -1;
+        for (size_t i = 0; i < ctx->pool.size(); i++) {
+            auto &b = ctx->pool[i];
+            if (!b.in_use && b.size >= want && (best < 0 || b.size < ctx->pool[best].size)) best = (int)i;
+        }
+        if (best >= 0) { ctx->pool[best].in_use = true; return ctx->pool[best].ptr; }
+        ks_pool_trim(ctx); // ... else give the cached blocks back and retry once
         e = hipMalloc(&p, want);
     }
     if (e != hipSuccess) {

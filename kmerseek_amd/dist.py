@@ -131,12 +131,15 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
         # when an id does not fit its field, and every rank then takes the unpacked exchange)
         raise ValueError(f"id bases ({qid_base}, {tid_base}) do not fit id_counts {tuple(id_counts)}")
 
-    if world == 1 and on_device and qid_base == 0 and tid_base == 0:
+    if (world == 1 and on_device and qid_base == 0 and tid_base == 0
+            and hits._ctx.stream == torch.cuda.current_stream(dev).cuda_stream):
         # one rank, nothing to shift: the columns of the hit list themselves, as torch views (no 20-byte-per-row D2D copy:
-        # 0.9 ms of a 3.9 ms step at 31 M rows); each tensor keeps the ks_hits object alive
+        # 0.9 ms of a 3.9 ms step at 31 M rows); each tensor keeps the ks_hits object alive.  Only when the context launches
+        # on torch's current stream: the block goes back to the context's pool when the last view dies, and the next ks_*
+        # call may hand it out again — stream order is what keeps that call's kernels behind whatever torch kernels the
+        # consumer queued on the views.  A context with a stream of its own gets copies (below).
         views = _hit_columns_as_torch(hits, n_local, dev)
         if views is not None:
-            own_stream_sync()
             return views
 
     if world > 1 and id_counts is not None:
@@ -208,12 +211,22 @@ class _DeviceColumn:
     """A device array owned by a library object, seen through __cuda_array_interface__ (torch.as_tensor makes a view of it
     and holds a reference to this object, which holds the owner)."""
 
-    def __init__(self, ptr: int, n: int, typestr: str, owner):
-        self._owner = owner
+    def __init__(self, ptr: int, n: int, typestr: str, owner, dev=None):
+        self._owner, self._dev = owner, dev
         owner.pin()  # an explicit owner.free() waits for the views
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
     def __del__(self):
+        try:
+            # The consumer may have queued torch kernels on the view.  They were ordered before the context's next launch when
+            # the view was made (same stream); if torch's current stream is another one by now, wait for it before the block
+            # can go back to the pool.
+            import torch
+            cur = torch.cuda.current_stream(self._dev)
+            if cur.cuda_stream != self._owner._ctx.stream:
+                cur.synchronize()
+        except Exception:
+            pass
         try:
             self._owner.unpin()
         except Exception:
@@ -229,9 +242,21 @@ def _hit_columns_as_torch(hits, n: int, dev):
         ptrs = hits.device_ptrs()
         if not all(ptrs):
             return None
-        return tuple(torch.as_tensor(_DeviceColumn(p, n, t, hits), device=dev) for p, t in zip(ptrs, ("<i4", "<i4", "<i4", "<i8")))
+        return tuple(torch.as_tensor(_DeviceColumn(p, n, t, hits, dev), device=dev) for p, t in zip(ptrs, ("<i4", "<i4", "<i4", "<i8")))
     except Exception:  # (a torch build without the interface: the copy path below does the same job)
         return None
+
+
+def sketch_columns_as_torch(sk, dev):
+    """(offsets i64[n_seqs + 1], hashes i64[n_hashes], abunds i32[n_hashes]) of a device-resident ``engine.Sketches`` as torch
+    views (same lifetime rules as the hit columns: the views pin the object)."""
+    import torch
+    po, ph, pa = sk.device_ptrs()
+    n, m = sk.n_seqs, sk.n_hashes
+    offs = torch.as_tensor(_DeviceColumn(po, n + 1, "<i8", sk, dev), device=dev)
+    if m == 0:
+        return offs, torch.empty(0, dtype=torch.int64, device=dev), torch.empty(0, dtype=torch.int32, device=dev)
+    return offs, torch.as_tensor(_DeviceColumn(ph, m, "<i8", sk, dev), device=dev), torch.as_tensor(_DeviceColumn(pa, m, "<i4", sk, dev), device=dev)
 
 
 class PendingGather:
@@ -240,14 +265,28 @@ class PendingGather:
     kernels, is the step of an index-sharded all-vs-all, and the collective (RCCL runs it on a stream of its own) moves the
     previous step's rows while the next step is sketched and joined."""
 
-    def __init__(self, finish=None, result=None):
-        self._finish, self._result = finish, result
+    def __init__(self, finish=None, result=None, release=None):
+        self._finish, self._result, self._release = finish, result, release
 
     def finish(self):
         if self._finish is not None:
-            self._result = self._finish()
-            self._finish = None
+            try:
+                self._result = self._finish()
+            finally:
+                self._finish = None
+                self._drop()
         return self._result
+
+    def _drop(self):
+        if self._release is not None:
+            rel, self._release = self._release, None
+            rel()
+
+    def __del__(self):  # (an exchange nobody completed: the hit list it kept for a repeat is let go)
+        try:
+            self._drop()
+        except Exception:
+            pass
 
 
 def _gather_packed(hits, on_device, n_local, counts, qid_base, tid_base, qbits, tbits, dev, own_stream_sync, torch_stream_sync):
@@ -339,7 +378,8 @@ def begin_all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, dev
     """``all_gather_hits_device`` in two halves: the rows are packed and the collective is STARTED here; ``finish()`` of the
     returned object delivers the gathered columns.  Only the transport-word exchange of device-resident hits on more than one
     rank really runs in the background (the count exchange before it is a few bytes); everything else completes here.
-    The hit list may be freed as soon as this returns (its rows are in the send block)."""
+    ``hits.free()`` may be called as soon as this returns: the object is pinned until ``finish()`` (which repeats the exchange
+    with unpacked columns when the escape lists overflow) and released then."""
     import torch
     rank, world = world_info()
     dev = device if device is not None else torch.device("cpu")
@@ -365,24 +405,23 @@ def begin_all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, dev
     qbits, tbits = _bits_for(id_counts[0]), _bits_for(id_counts[1])
     if n_local and (qid_base >= max(id_counts[0], 1) or tid_base >= max(id_counts[1], 1)):
         raise ValueError(f"id bases ({qid_base}, {tid_base}) do not fit id_counts {tuple(id_counts)}")
-    # (a private handle: the caller frees `hits` right away, the completion still needs its context)
+    # The hit list stays alive until finish(): when some rank has more rows with wide values than the escape lists take, the
+    # exchange is repeated right there with the columns unpacked — the caller may still call hits.free() at once (pinned: the
+    # release waits), as the docstring says.
+    hits.pin()
     fin = _gather_packed_begin(hits, True, n_local, counts, qid_base, tid_base, qbits, tbits, dev, own_stream_sync, torch_stream_sync,
                                async_op=True)
 
-    class _CtxOnly:  # what _order_by_qid needs of a hit list
-        _ctx = ctx
-
     def finish():
         out = fin()
-        if out is None:
-            raise RuntimeError("more rows with wide values than the escape lists take: repeat this exchange with "
-                               "all_gather_hits_device (unpacked columns)")
+        if out is None:  # (every rank sees the same escape counts, so every rank takes this branch)
+            return all_gather_hits_device(hits, qid_base, tid_base, device, sharded, order, id_counts=None)
         qid, tid, isect, nw = out
         if sharded == "index" and order == "qid" and qid.numel():
-            qid, tid, isect, nw = _order_by_qid(_CtxOnly, True, (qid, tid, isect, nw), counts, id_counts[0], dev, own_stream_sync,
+            qid, tid, isect, nw = _order_by_qid(hits, True, (qid, tid, isect, nw), counts, id_counts[0], dev, own_stream_sync,
                                                 torch_stream_sync)
         return qid, tid, isect, nw
-    return PendingGather(finish=finish)
+    return PendingGather(finish=finish, release=hits.unpin)
 
 
 def all_gather_hits(hits, qid_base: int = 0, tid_base: int = 0, device=None, sharded: str = "queries",

@@ -98,7 +98,14 @@ class _FollowDebugEnv:
 
 
 class Context:
-    """One HIP device + stream + workspace (ks_ctx).  Not thread-safe: one per host thread."""
+    """One HIP device + stream + workspace (ks_ctx).  Not thread-safe: one per host thread.
+
+    stream: None — the context creates a non-blocking stream of its own; a raw ``hipStream_t`` value (e.g.
+    ``torch.cuda.current_stream().cuda_stream``) — the context launches there, so its work is ordered with the caller's.
+    0 is what torch reports for the device's default (null) stream: it is passed on as ``hipStreamLegacy``, and
+    ``Context.stream`` reports it as 0 again, so ``ctx.stream == torch.cuda.current_stream().cuda_stream`` holds."""
+
+    _HIP_STREAM_LEGACY = 1  # hip_runtime_api.h: #define hipStreamLegacy ((hipStream_t)1)
 
     def __init__(self, device: int = 0, stream: Optional[int] = None, follow_debug_env: bool = False):
         self._L = _lib.load()
@@ -106,14 +113,22 @@ class Context:
         if follow_debug_env:
             self._L = _FollowDebugEnv(self._L, self)
         h = C.c_void_p()
-        st = self._L.ks_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        sp = None if stream is None else C.c_void_p(int(stream) if int(stream) != 0 else self._HIP_STREAM_LEGACY)
+        st = self._L.ks_ctx_create(int(device), sp, C.byref(h))
         if st != _lib.KS_OK:
             raise KmerseekError(st, f"ks_ctx_create(device={device}) failed: {self._L.ks_status_string(st).decode()}"
                                     " — the HIP path has no CPU fallback")
         self._h = h
         self.device = device
+        self._pinned, self._close_pending = 0, False
 
     def close(self):
+        """Destroy the context (its pool, stream, pinned blocks).  While views of library-owned device arrays are alive
+        (`_Owned.pin`: the world-size-1 hit exchange hands out torch views) the destruction waits for the last of them —
+        a view must never outlive the memory it points into."""
+        if getattr(self, "_pinned", 0) > 0:
+            self._close_pending = True
+            return
         if getattr(self, "_h", None):
             self._L.ks_ctx_destroy(self._h)
             self._h = None
@@ -137,7 +152,8 @@ class Context:
 
     @property
     def stream(self) -> int:
-        return int(self._L.ks_ctx_stream(self._h) or 0)
+        v = int(self._L.ks_ctx_stream(self._h) or 0)
+        return 0 if v == self._HIP_STREAM_LEGACY else v
 
     def synchronize(self):
         self._check(self._L.ks_ctx_synchronize(self._h))
@@ -386,12 +402,17 @@ class _Owned:
 
     def pin(self):
         self._pins += 1
+        self._ctx._pinned += 1
 
     def unpin(self):
         self._pins -= 1
+        self._ctx._pinned -= 1
         if self._pins == 0 and self._free_pending:
             self._free_pending = False
             self.free()
+        if self._ctx._pinned == 0 and self._ctx._close_pending:
+            self._ctx._close_pending = False
+            self._ctx.close()
 
     def __del__(self):
         try:
@@ -424,6 +445,12 @@ class Sketches(_Owned):
     def posting_bytes(self) -> int:
         """Bytes per partitioned query posting: 12, 10 (big fingerprint indexes at scaled = 1) or 0 (none attached)."""
         return (0, 12, 10)[int(self._ctx._L.ks_sketches_has_postings(self._h))]
+
+    def device_ptrs(self) -> Tuple[int, int, int]:
+        """Raw device pointers of the CSR (offsets u64[n_seqs + 1], hashes u64[n_hashes], abunds u32[n_hashes])."""
+        L = self._ctx._L
+        return tuple(int(f(self._h) or 0) for f in (L.ks_sketches_device_offsets, L.ks_sketches_device_hashes,
+                                                    L.ks_sketches_device_abunds))
 
     def union(self) -> "Sketches":
         """Combined sketch: sorted unique hashes of all sequences with summed abundances (one sequence)."""

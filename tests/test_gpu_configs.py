@@ -133,11 +133,30 @@ def test_dist_layer_single_rank_gpu(ctx):
     assert np.array_equal(got[3].cpu().numpy().view(np.uint64), want[3])
     ptrs = h.device_ptrs()
     assert all(p != 0 for p in ptrs)
-    # one rank, no id shift: the columns themselves come back as torch views (no D2D copy), and they keep the hit list alive
-    views = ksd.all_gather_hits_device(h, device=dev)
-    assert views[0].data_ptr() == ptrs[0] and views[3].data_ptr() == ptrs[3]
+    # one rank, no id shift, but this context launches on a stream of its own: copies, not views (advisor r3: a view's block
+    # goes back to the pool when the view dies, and only stream order protects the torch kernels still reading it)
+    copies = ksd.all_gather_hits_device(h, device=dev)
+    assert copies[0].data_ptr() != ptrs[0] and copies[3].data_ptr() != ptrs[3]
+    for g, w_ in zip(copies, want):
+        assert np.array_equal(g.cpu().numpy().view(w_.dtype), w_)
+    # a context on torch's current stream: the columns themselves come back as torch views (no D2D copy); they keep the hit
+    # list alive past an explicit free(), and the context alive past close()
+    c2 = ks.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+    h2 = ksd.gpu_search_fn(c2, 10, 1, "protein")(q[0], q[1], t[0], t[1])
+    ptrs2 = h2.device_ptrs()
+    views = ksd.all_gather_hits_device(h2, device=dev)
+    assert views[0].data_ptr() == ptrs2[0] and views[3].data_ptr() == ptrs2[3]
+    h2.free()
+    assert h2._h is not None  # (deferred: the views pin it)
+    c2.close()
+    assert c2._h is not None  # (deferred too)
+    doubled = [v * 2 for v in views]  # torch kernels queued on the views
     for g, w_ in zip(views, want):
         assert np.array_equal(g.cpu().numpy().view(w_.dtype), w_)
+    for g, w_ in zip(doubled, want):
+        assert np.array_equal(g.cpu().numpy().view(w_.dtype), w_ * 2)
+    del views, g
+    assert h2._h is None and c2._h is None  # the last view took the hit list and the context with it
     # an id that does not fit its field is not packed into its neighbour: the escape count says "take the other exchange"
     n = h.count
     small = torch.zeros(n + 1 + 2 * 64, dtype=torch.int64, device=dev)
@@ -193,3 +212,78 @@ def test_dist_layer_single_rank_gpu(ctx):
                 assert np.array_equal(got_col[:n], w_.astype(dt) + dt(add)) and np.array_equal(got_col[n:], w_.astype(dt) + dt(add))
     finally:
         ksd._dist = real
+
+
+def test_pipelined_exchange_on_device_with_escape_overflow(monkeypatch):
+    """dist.begin_all_gather_hits_device / PendingGather.finish on DEVICE tensors (advisor r3: the gloo tests pass host tuples
+    and take the synchronous path): packed exchange started asynchronously, the hit list freed right after begin, the next
+    step's kernels queued in between, unpack + counting merge inside finish() — and, with 8 value bits, more escapes than the
+    lists take, so finish() repeats the exchange with unpacked columns by itself.  Two ranks that hold the same shard stand in
+    for the collective (one GPU here)."""
+    dev = torch.device("cuda", 0)
+
+    class _Work:
+        def wait(self):
+            return True
+
+    class _TwoRanks:
+        calls = []
+
+        @staticmethod
+        def all_gather_into_tensor(recv, send, async_op=False):
+            half = send.numel()
+            recv[:half] = send
+            recv[half:2 * half] = send
+            _TwoRanks.calls.append((int(half), bool(async_op)))
+            return _Work() if async_op else None
+
+    monkeypatch.setattr(ksd, "world_info", lambda: (0, 2))
+    monkeypatch.setattr(ksd, "_dist", lambda: _TwoRanks)
+    for own_stream in (False, True):
+        c = ks.Context(0, stream=None if own_stream else torch.cuda.current_stream(dev).cuda_stream)
+        p = synth.proteome(3000, stream=70)
+        S = c.sketch_batch(p[0], p[1], 7, 1, "protein")
+        ix = c.index_build(S)
+        for id_counts, overflow in (((3000, 3000), False), ((1 << 24, 1 << 24), True)):
+            h = c.search(ix, S)
+            want = h.to_host()
+            n = h.count
+            qbits, tbits = ksd._bits_for(id_counts[0]), ksd._bits_for(id_counts[1])
+            vmax = (1 << ((64 - qbits - tbits) // 2)) - 1
+            n_esc = int(((want[2] >= vmax) | (want[3] >= vmax)).sum())
+            esc_cap = max(1024, ((n + 63) // 64 * 64) // 64) // 2 * 2
+            assert (n_esc > esc_cap) == overflow, (n_esc, esc_cap)
+            _TwoRanks.calls.clear()
+            pend = ksd.begin_all_gather_hits_device(h, device=dev, sharded="index", order="qid", id_counts=id_counts)
+            assert _TwoRanks.calls[-1][1] is True  # the data exchange was started asynchronously
+            h.free()                               # allowed right away: the list is pinned until finish()
+            assert h._h is not None
+            nxt = c.search(ix, S)                  # the next step's kernels run between begin and finish
+            got = pend.finish()
+            assert h._h is None
+            assert nxt.count == n
+            nxt.free()
+            if overflow:  # the repeat inside finish(): a count exchange and the unpacked columns, both synchronous
+                assert [a for _, a in _TwoRanks.calls[-2:]] == [False, False]
+            cat = [np.concatenate([w, w]) for w in want]
+            order = np.argsort(cat[0], kind="stable")  # by qid, rank blocks in rank order inside a query
+            for g, w_ in zip(got, cat):
+                assert g.device.type == "cuda"
+                assert np.array_equal(g.cpu().numpy().view(w_.dtype), w_[order])
+        # an id beyond the declared range has no place in the merged order: the merge fails instead of leaving a gap
+        h = c.search(ix, S)
+        cols = [torch.empty(h.count, dtype=t, device=dev) for t in (torch.int32, torch.int32, torch.int32, torch.int64)]
+        torch.cuda.current_stream(dev).synchronize()
+        h.copy_to_device(*[x.data_ptr() for x in cols])
+        c.synchronize()
+        outs = [torch.empty_like(x) for x in cols]
+        torch.cuda.current_stream(dev).synchronize()
+        with pytest.raises(ks.KmerseekError) as e:
+            c.merge_hits_by_qid_device(*[x.data_ptr() for x in cols], [h.count], 2000, *[x.data_ptr() for x in outs])
+        assert "query id" in str(e.value)
+        c.merge_hits_by_qid_device(*[x.data_ptr() for x in cols], [h.count], 3000, *[x.data_ptr() for x in outs])
+        c.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(cols, outs))
+        h.free(); ix.free(); S.free()
+        del cols, outs
+        c.close()

@@ -1,7 +1,8 @@
 """BASELINE.json configs[3] and configs[4] at FULL size (1M-vs-1M protein k=10 scaled=1; 200k all-vs-all hp k=24 scaled=5):
 the code paths only these sizes reach — 16-bit join prefix, the S=18 sort prefix of the index build, 256 high digits in the
 bucket scatter, look-back chains over ~90k tiles — checked against the oracle on samples spread over the batch (first and
-last tiles included) and through size-independent properties.  bench.py runs the same workloads but asserts nothing."""
+last tiles included) and through size-independent properties; the entry bench.py times (ks_sketch_search_device, called
+with max_seq_len as the bench calls it) is held against the two-call result at the same size."""
 import os
 
 import numpy as np
@@ -56,6 +57,26 @@ def _oracle_rows(q_sk, t_sk, qids):
     return np.asarray(qids, np.uint32)[oq], ot, oi, ow
 
 
+def _check_one_call_entry(ctx, index, d_res, d_off, n, n_res, max_len, want_sk, want_rows, want_pairs, want_posting_bytes, defers):
+    """The timed entry of bench.py at the size it is timed at: same sketches, same rows as sketch_queries_device + search
+    (reference flow: src/python/kmerseek/sketch.py:28-40 then search.py:125-141), and no silent repeat."""
+    f0, s0, k0 = ctx.fused_stats(), ctx.search_stats(), ctx.sketch_stats()
+    Q1, H1 = ctx.sketch_search_device(index, d_res, d_off, n, n_res, max_seq_len=max_len)
+    f1, s1, k1 = ctx.fused_stats(), ctx.search_stats(), ctx.sketch_stats()
+    try:
+        assert f1["redos"] == f0["redos"], "the one-call entry fell back to the two plain calls"
+        assert f1["deferred"] - f0["deferred"] == (1 if defers else 0)
+        assert s1 == s0 and k1 == k0, (s0, s1, k0, k1)
+        assert Q1.posting_bytes == want_posting_bytes
+        assert H1.partition_path == 1 and H1.n_pair_instances == want_pairs and H1.count == len(want_rows[0])
+        for g, w in zip(Q1.to_host(), want_sk):
+            assert np.array_equal(g, w)
+        for g, w in zip(H1.to_host(), want_rows):
+            assert np.array_equal(g, w)
+    finally:
+        H1.free(); Q1.free()
+
+
 def _csr_properties(o, m, a, n_windows, scaled):
     assert o[0] == 0 and np.all(o[1:] >= o[:-1]) and int(o[-1]) == len(m) == len(a)
     inner = np.ones(len(m), bool)
@@ -107,6 +128,11 @@ def test_baseline_configs3_1M_vs_1M_protein_k10_full_size(ctx):
         for g, w in zip(H2.to_host(), (qid, tid, isect, nw)):
             assert np.array_equal(g, w)
         H2.free(); Q2.free()
+        # the entry bench.py times, as bench.py calls it (a 1M batch of <= 3000-aa proteins plans with one round trip: its
+        # tile bound is too loose to launch on, so nothing is deferred — DESIGN.md 3.2)
+        assert Q.posting_bytes == 10
+        max_len = int((q[1][1:] - q[1][:-1]).max())
+        _check_one_call_entry(ctx, index, d[2].ptr, d[3].ptr, n, len(q[0]), max_len, q_sk, (qid, tid, isect, nw), n_pairs, 10, defers=False)
         # the 3-pass partitioned index build == the 8-pass LSD sort (forced)
         os.environ["KS_DEBUG_INDEX_LSD"] = "1"
         try:
@@ -157,6 +183,10 @@ def test_baseline_configs4_200k_all_vs_all_hp_k24_full_size(ctx):
         sel = np.isin(qid, sample.astype(np.uint32))
         assert np.array_equal(qid[sel], oq) and np.array_equal(tid[sel], ot)
         assert np.array_equal(isect[sel], oi) and np.array_equal(nw[sel], ow)
+        # the entry bench.py times (config4_index_sharded), as bench.py calls it: read-back deferred into the search's first wait
+        max_len = int((p[1][1:] - p[1][:-1]).max())
+        _check_one_call_entry(ctx, index, dr.ptr, do.ptr, n, len(p[0]), max_len, sk, (qid, tid, isect, nw), H.n_pair_instances, 12,
+                              defers=True)
         # index sharded 4 ways by target id, hit lists exchanged through the device-resident path: gathered == unsharded
         dev = torch.device("cuda", 0)
         parts = []
