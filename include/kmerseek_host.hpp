@@ -8,10 +8,15 @@
 //   * persistence is a flat file in this library's own format, not RocksDB (storage is out of
 //     scope; `save_state` / `load_state` keep the API shape and the `NoSavedState` error);
 //   * B/Z/J resolution draws from a seeded SplitMix64 stream instead of rand::rng() (aminoacid.rs:48);
-//   * FASTA input: plain or gzip (zlib).  bz2 / xz / zstd inputs raise ParseError (needletail's niffler is absent).
+//   * FASTA input: plain, gzip, zstd, bzip2 or xz, told apart by magic number as needletail does (ks_input.cpp; libzstd / libbz2 /
+//     liblzma are bound at run time); a truncated archive raises ParseError;
+//   * `search` / `search_fasta` are ADDED: the reference's crate builds and stores signatures and has no
+//     search of its own (index.rs ends at :1017); its only search is branchwater manysearch on the Python side
+//     (src/python/kmerseek/search.py:125-141), whose rows these methods return for the signatures the index holds.
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <optional>
@@ -22,6 +27,8 @@
 #include <vector>
 
 struct ks_ctx;
+struct ks_index;
+struct ks_sketches;
 
 namespace kmerseek {
 
@@ -68,6 +75,21 @@ class ProteinSignature {
     const std::string *get_raw_sequence() const { return raw_sequence ? &*raw_sequence : nullptr; }
 };
 
+// One row of a search: the 22 columns branchwater manysearch writes for a (query, match) pair that shares at least one
+// hash (src/python/kmerseek/search.py:125-141; values pinned by the reference's tests/test_search.py:33-39).
+// Integer columns come from the GPU join (intersect_hashes, n_weighted_found); the ratios are f64 arithmetic on them.
+struct SearchResult {
+    std::string query_name, query_md5, match_name, match_md5, moltype; // *_md5: sourmash md5sum = MD5(str(3k) || str(min) ...)
+    uint64_t intersect_hashes = 0;
+    uint32_t ksize = 0;  // 3 * protein k-mer size, as sourmash reports it
+    uint32_t scaled = 0;
+    double containment = 0, jaccard = 0, max_containment = 0;
+    double average_abund = 0, median_abund = 0, std_abund = 0; // over the match's abundances of the shared hashes (population std)
+    double query_containment_ani = 0, match_containment_ani = 0, average_containment_ani = 0, max_containment_ani = 0;
+    uint64_t n_weighted_found = 0, total_weighted_hashes = 0;
+    double containment_target_in_query = 0, f_weighted_target_in_query = 0;
+};
+
 class ProteomeIndexBuilder;
 
 class ProteomeIndex {
@@ -98,6 +120,16 @@ class ProteomeIndex {
     // index.rs:907-961 (plain / gzip FASTA); batch_size = records per GPU batch
     void process_fasta(const std::string &fasta_path, uint32_t progress_interval, size_t batch_size);
 
+    // ---- search (added; see the header comment).  The stored signatures (get_signatures, index.rs:642-652) are the targets:
+    // they are laid out once as a device-resident ks_index (rebuilt after the next store_signatures) and every call is one
+    // ks_sketch_search of the whole query batch.  Queries go through the same pre-step as create_protein_signature
+    // (validate / resolve; `upper` = the FASTA path's upper-casing); rows come out ordered by (query, match key).
+    std::vector<SearchResult> search(const std::vector<std::pair<std::string, std::string>> &queries, bool upper = false);
+    // every record of a FASTA file (plain / gzip / zstd / bzip2 / xz) as queries, `batch_size` records per GPU batch
+    std::vector<SearchResult> search_fasta(const std::string &fasta_path, size_t batch_size = 100000);
+    // the two-line form a consumer streams into the reference's CSV: column names in file order
+    static const std::vector<std::string> &search_columns();
+
     void save_state();                                                   // index.rs:227-269 (own file format)
     static std::unique_ptr<ProteomeIndex> load(const std::string &path, int device = 0); // index.rs:430-511
 
@@ -126,6 +158,19 @@ class ProteomeIndex {
     uint64_t rng_seed_ = 0x6b6d6572ULL;
     std::map<std::string, ProteinSignature> signatures_; // pseudo-md5 -> signature (same-key records overwrite, index.rs:817-820)
     std::vector<uint64_t> combined_mins_, combined_abunds_;
+    // device-resident search index over signatures_ (targets in map order), built on first use by ensure_device_index()
+    ks_sketches *dev_targets_ = nullptr;
+    ks_index *dev_index_ = nullptr;
+    std::vector<const ProteinSignature *> dev_order_; // target id -> signature
+    std::vector<std::string> dev_md5_;                // target id -> sourmash md5sum (filled on demand)
+    std::vector<uint64_t> dev_total_abund_;           // target id -> sum of abundances
+    void ensure_device_index();
+    void drop_device_index();
+    // validate / resolve + pack: the host pre-step shared by create_protein_signatures and search
+    void prepare_records(const std::vector<std::pair<std::string, std::string>> &records, bool upper,
+                         std::vector<std::string> &processed, std::vector<uint64_t> &offs, std::vector<uint8_t> &res);
+    void for_each_fasta_batch(const std::string &fasta_path, size_t batch_size, uint32_t progress_interval,
+                              const std::function<void(std::vector<std::pair<std::string, std::string>> &)> &fn, size_t *n_records);
 };
 
 // index.rs:2975-3061

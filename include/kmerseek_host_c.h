@@ -34,6 +34,16 @@ int ksh_index_add_records(ksh_index *ix, const char *const *sequences, const cha
 /* process_fasta (:907-961) */
 int ksh_index_process_fasta(ksh_index *ix, const char *fasta_path, uint32_t progress_interval, uint64_t batch_size,
                             char *err, size_t err_cap);
+/* search (added — SURVEY 8(b); see include/kmerseek_host.hpp): (sequence, name) query records, or every record of a FASTA
+ * file, against the signatures the index holds.  One GPU call per batch (ks_sketch_search against a device-resident ks_index
+ * built once from the stored signatures and dropped by the next store).  *json_out (ksh_string_free): an array of row objects
+ * with the 22 columns of branchwater manysearch (src/python/kmerseek/search.py:125-141), f64 columns printed with 17
+ * significant digits.  upper: FASTA-path upper-casing of the queries (src/rust/index.rs:1000); an invalid residue is the same
+ * error create_protein_signature raises. */
+int ksh_index_search(ksh_index *ix, const char *const *sequences, const char *const *names, uint32_t n, int upper,
+                     char **json_out, char *err, size_t err_cap);
+int ksh_index_search_fasta(ksh_index *ix, const char *fasta_path, uint64_t batch_size, char **json_out, char *err,
+                           size_t err_cap);
 uint64_t ksh_index_signature_count(const ksh_index *ix);
 uint64_t ksh_index_combined_minhash_size(const ksh_index *ix);
 uint32_t ksh_index_ksize(const ksh_index *ix);

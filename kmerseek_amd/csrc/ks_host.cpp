@@ -5,6 +5,7 @@
 
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -72,6 +73,7 @@ ProteomeIndex::ProteomeIndex(const std::string &path, uint32_t ksize, uint32_t s
 }
 
 ProteomeIndex::~ProteomeIndex() {
+    drop_device_index();
     if (ctx_) ks_ctx_destroy(ctx_);
 }
 
@@ -103,13 +105,11 @@ ProteinSignature ProteomeIndex::create_protein_signature(const std::string &sequ
     return std::move(v[0]);
 }
 
-std::vector<ProteinSignature> ProteomeIndex::create_protein_signatures(
-    const std::vector<std::pair<std::string, std::string>> &records, bool upper) {
+void ProteomeIndex::prepare_records(const std::vector<std::pair<std::string, std::string>> &records, bool upper,
+                                    std::vector<std::string> &processed, std::vector<uint64_t> &offs, std::vector<uint8_t> &res) {
     const size_t n = records.size();
-    std::vector<ProteinSignature> out(n);
-    if (n == 0) return out;
     // ---- host pre-step, parallel over records: validate / resolve (aminoacid.rs:74-105)
-    std::vector<std::string> processed(n);
+    processed.assign(n, std::string());
     std::vector<ks_residue_error> errs(n);
     std::vector<int> status(n, KS_OK);
     unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 16));
@@ -139,11 +139,23 @@ std::vector<ProteinSignature> ProteomeIndex::create_protein_signatures(
             e.residue = (char)errs[i].residue; e.position = errs[i].position; e.seq_index = i;
             throw e;
         }
-    // ---- pack and run the two batched GPU calls
-    std::vector<uint64_t> offs(n + 1, 0);
+    // ---- pack: the batch layout of the C ABI
+    offs.assign(n + 1, 0);
     for (size_t i = 0; i < n; i++) offs[i + 1] = offs[i] + processed[i].size();
-    std::vector<uint8_t> res(offs[n] + 1);
+    res.assign(offs[n] + 1, 0);
     for (size_t i = 0; i < n; i++) memcpy(res.data() + offs[i], processed[i].data(), processed[i].size());
+}
+
+std::vector<ProteinSignature> ProteomeIndex::create_protein_signatures(
+    const std::vector<std::pair<std::string, std::string>> &records, bool upper) {
+    const size_t n = records.size();
+    std::vector<ProteinSignature> out(n);
+    if (n == 0) return out;
+    std::vector<std::string> processed;
+    std::vector<uint64_t> offs;
+    std::vector<uint8_t> res;
+    prepare_records(records, upper, processed, offs, res);
+    // ---- the two batched GPU calls
     ks_params p{ksize_, scaled_, moltype_id_, 0, SEED};
     ks_sketches *S = nullptr;
     int st = ks_sketch_batch(ctx_, res.data(), offs.data(), (uint32_t)n, &p, &S);
@@ -219,6 +231,7 @@ void ProteomeIndex::process_kmers(const std::string &sequence, ProteinSignature 
 }
 
 void ProteomeIndex::store_signatures(std::vector<ProteinSignature> sigs) {
+    drop_device_index(); // the search index is laid out over signatures_: it is rebuilt on the next search
     // combined sketch: union with summed abundances (index.rs:803-827), done on the GPU for the batch and
     // merged into the running (sorted) combined sketch on the host
     std::vector<uint64_t> offs(sigs.size() + 1, 0);
@@ -266,9 +279,11 @@ void ProteomeIndex::store_signatures_batch(const std::vector<ProteinSignature> &
     store_signatures(std::vector<ProteinSignature>(sigs));
 }
 
-void ProteomeIndex::process_fasta(const std::string &fasta_path, uint32_t progress_interval, size_t batch_size) {
-    if (progress_interval > 0) printf("Reading FASTA file with automatic compression detection and parallel processing...\n");
-    // plain / gzip / zstd / bzip2 / xz by magic number (ks_input.h), as needletail's parse_fastx_file does (index.rs:907-961)
+// FASTA records of a plain / gzip / zstd / bzip2 / xz file (ks_input.h: by magic number, as needletail's parse_fastx_file does,
+// index.rs:907-961), handed to `fn` in batches of `batch_size` (sequence, full header line) pairs.
+void ProteomeIndex::for_each_fasta_batch(const std::string &fasta_path, size_t batch_size, uint32_t progress_interval,
+                                         const std::function<void(std::vector<std::pair<std::string, std::string>> &)> &fn,
+                                         size_t *n_records) {
     std::string oerr;
     std::unique_ptr<KsInput> in(KsInput::open(fasta_path.c_str(), oerr));
     if (!in) throw IndexError(IndexError::ParseError, "Parse error: " + oerr);
@@ -283,7 +298,7 @@ void ProteomeIndex::process_fasta(const std::string &fasta_path, uint32_t progre
         seq.clear(); id.clear();
         record_count++;
         if (batch.size() >= batch_size) {
-            store_signatures(create_protein_signatures(batch, true));
+            fn(batch);
             batch.clear();
         }
         if (progress_interval > 0 && record_count % progress_interval == 0) printf("Read %zu sequences...\n", record_count);
@@ -318,9 +333,227 @@ void ProteomeIndex::process_fasta(const std::string &fasta_path, uint32_t progre
     }
     if (!line.empty()) { take_line(); line.clear(); } // last line without a terminator
     flush_record();
-    if (!batch.empty()) store_signatures(create_protein_signatures(batch, true));
+    if (!batch.empty()) fn(batch);
+    if (n_records) *n_records = record_count;
+}
+
+void ProteomeIndex::process_fasta(const std::string &fasta_path, uint32_t progress_interval, size_t batch_size) {
+    if (progress_interval > 0) printf("Reading FASTA file with automatic compression detection and parallel processing...\n");
+    size_t record_count = 0;
+    for_each_fasta_batch(fasta_path, batch_size, progress_interval,
+                         [&](std::vector<std::pair<std::string, std::string>> &batch) { store_signatures(create_protein_signatures(batch, true)); },
+                         &record_count);
     save_state();
     if (progress_interval > 0) printf("Successfully processed and stored %zu sequences.\n", record_count);
+}
+
+// ---- search (added: SURVEY 8(b); rows of branchwater manysearch, src/python/kmerseek/search.py:125-141) ------------------
+namespace {
+// MD5 (RFC 1321), for sourmash's md5sum of a sketch: MD5(ascii(3k) || ascii(min) || ...)
+struct Md5 {
+    uint32_t a = 0x67452301u, b = 0xefcdab89u, c = 0x98badcfeu, d = 0x10325476u;
+    uint64_t len = 0;
+    uint8_t buf[64];
+    size_t fill = 0;
+    static uint32_t rol(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+    void block(const uint8_t *p) {
+        static const uint32_t K[64] = {
+            0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1,
+            0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453,
+            0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a, 0xfffa3942,
+            0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05,
+            0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d,
+            0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+        static const int S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
+                                  4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+        uint32_t m[16];
+        for (int i = 0; i < 16; i++) m[i] = (uint32_t)p[4 * i] | (uint32_t)p[4 * i + 1] << 8 | (uint32_t)p[4 * i + 2] << 16 | (uint32_t)p[4 * i + 3] << 24;
+        uint32_t A = a, B = b, C = c, D = d;
+        for (int i = 0; i < 64; i++) {
+            uint32_t f;
+            int g;
+            if (i < 16) { f = (B & C) | (~B & D); g = i; }
+            else if (i < 32) { f = (D & B) | (~D & C); g = (5 * i + 1) & 15; }
+            else if (i < 48) { f = B ^ C ^ D; g = (3 * i + 5) & 15; }
+            else { f = C ^ (B | ~D); g = (7 * i) & 15; }
+            const uint32_t t = D;
+            D = C; C = B;
+            B = B + rol(A + f + K[i] + m[g], S[i]);
+            A = t;
+        }
+        a += A; b += B; c += C; d += D;
+    }
+    void update(const void *data, size_t n) {
+        const uint8_t *p = (const uint8_t *)data;
+        len += n;
+        while (n) {
+            const size_t take = std::min(n, 64 - fill);
+            memcpy(buf + fill, p, take);
+            fill += take; p += take; n -= take;
+            if (fill == 64) { block(buf); fill = 0; }
+        }
+    }
+    std::string hex() {
+        const uint64_t bits = len * 8;
+        const uint8_t one = 0x80, zero = 0;
+        update(&one, 1);
+        while (fill != 56) update(&zero, 1);
+        uint8_t l[8];
+        for (int i = 0; i < 8; i++) l[i] = (uint8_t)(bits >> (8 * i));
+        update(l, 8);
+        char out[33];
+        const uint32_t w[4] = {a, b, c, d};
+        for (int i = 0; i < 16; i++) snprintf(out + 2 * i, 3, "%02x", (w[i / 4] >> (8 * (i % 4))) & 0xffu);
+        return std::string(out, 32);
+    }
+};
+
+std::string sourmash_md5(const uint64_t *mins, size_t n, uint32_t protein_ksize) {
+    Md5 m;
+    char b[32];
+    int l = snprintf(b, sizeof b, "%u", protein_ksize * PROTEIN_TO_MINHASH_RATIO);
+    m.update(b, (size_t)l);
+    for (size_t i = 0; i < n; i++) {
+        l = snprintf(b, sizeof b, "%llu", (unsigned long long)mins[i]);
+        m.update(b, (size_t)l);
+    }
+    return m.hex();
+}
+} // namespace
+
+const std::vector<std::string> &ProteomeIndex::search_columns() {
+    static const std::vector<std::string> cols = {
+        "query_name", "query_md5", "match_name", "containment", "intersect_hashes", "ksize", "scaled", "moltype", "match_md5", "jaccard",
+        "max_containment", "average_abund", "median_abund", "std_abund", "query_containment_ani", "match_containment_ani",
+        "average_containment_ani", "max_containment_ani", "n_weighted_found", "total_weighted_hashes", "containment_target_in_query",
+        "f_weighted_target_in_query"};
+    return cols;
+}
+
+void ProteomeIndex::drop_device_index() {
+    if (dev_index_) { ks_index_free(dev_index_); dev_index_ = nullptr; }
+    if (dev_targets_) { ks_sketches_free(dev_targets_); dev_targets_ = nullptr; }
+    dev_order_.clear(); dev_md5_.clear(); dev_total_abund_.clear();
+}
+
+void ProteomeIndex::ensure_device_index() {
+    if (dev_index_) return;
+    // targets = the stored signatures in key order (get_signatures, index.rs:642-652), as one CSR
+    const size_t n = signatures_.size();
+    std::vector<uint64_t> offs(n + 1, 0);
+    dev_order_.clear(); dev_order_.reserve(n);
+    size_t i = 0;
+    for (auto &kv : signatures_) { dev_order_.push_back(&kv.second); offs[i + 1] = offs[i] + kv.second.mins.size(); i++; }
+    std::vector<uint64_t> h(offs[n] + 1);
+    std::vector<uint32_t> a(offs[n] + 1);
+    dev_total_abund_.assign(n, 0);
+    for (i = 0; i < n; i++) {
+        const ProteinSignature &g = *dev_order_[i];
+        for (size_t j = 0; j < g.mins.size(); j++) {
+            h[offs[i] + j] = g.mins[j];
+            a[offs[i] + j] = (uint32_t)std::min<uint64_t>(g.abunds[j], 0xffffffffu);
+            dev_total_abund_[i] += g.abunds[j];
+        }
+    }
+    dev_md5_.assign(n, std::string());
+    ks_params p{ksize_, scaled_, moltype_id_, 0, SEED};
+    int st = ks_sketches_from_host(ctx_, offs.data(), h.data(), a.data(), (uint32_t)n, &p, &dev_targets_);
+    if (st != KS_OK) { dev_targets_ = nullptr; throw gpu_error(ctx_, st, "ks_sketches_from_host"); }
+    st = ks_index_build(ctx_, dev_targets_, &dev_index_);
+    if (st != KS_OK) { dev_index_ = nullptr; drop_device_index(); throw gpu_error(ctx_, st, "ks_index_build"); }
+}
+
+std::vector<SearchResult> ProteomeIndex::search(const std::vector<std::pair<std::string, std::string>> &queries, bool upper) {
+    std::vector<SearchResult> rows;
+    const size_t nq = queries.size();
+    if (nq == 0 || signatures_.empty()) return rows;
+    if (nq > 0xfffffff0ULL) throw IndexError(IndexError::ValidationError, "Validation error: too many query records in one batch");
+    std::vector<std::string> processed;
+    std::vector<uint64_t> offs;
+    std::vector<uint8_t> res;
+    prepare_records(queries, upper, processed, offs, res);
+    ensure_device_index();
+    // ---- one call: sketch the query batch and join it against the resident index
+    ks_sketches *S = nullptr;
+    ks_hits *H = nullptr;
+    int st = ks_sketch_search(ctx_, dev_index_, res.data(), offs.data(), (uint32_t)nq, &S, &H);
+    if (st != KS_OK) throw gpu_error(ctx_, st, "ks_sketch_search");
+    const uint64_t nh = ks_hits_count(H);
+    std::vector<uint32_t> qid(nh + 1), tid(nh + 1), isect(nh + 1);
+    std::vector<uint64_t> nw(nh + 1);
+    std::vector<uint64_t> qo(nq + 1), qm(ks_sketches_n_hashes(S) + 1);
+    st = ks_hits_copy_to_host(ctx_, H, qid.data(), tid.data(), isect.data(), nw.data());
+    if (st == KS_OK) st = ks_sketches_copy_to_host(ctx_, S, qo.data(), qm.data(), nullptr);
+    ks_hits_free(H);
+    ks_sketches_free(S);
+    if (st != KS_OK) throw gpu_error(ctx_, st, "copy of the search result");
+    // ---- rows: f64 ratios of the integer results (formulas: SURVEY.md 8(a) row a10)
+    rows.reserve(nh);
+    const double k3 = (double)(ksize_ * PROTEIN_TO_MINHASH_RATIO);
+    std::vector<std::string> q_md5(nq);
+    std::vector<double> shared;
+    for (uint64_t r = 0; r < nh; r++) {
+        const uint32_t q = qid[r], t = tid[r];
+        const ProteinSignature &g = *dev_order_[t];
+        const uint64_t *qmins = qm.data() + qo[q];
+        const size_t n_q = (size_t)(qo[q + 1] - qo[q]), n_t = g.mins.size();
+        // the match's abundances of the shared hashes: a sorted merge of the two sketches
+        shared.clear();
+        for (size_t i = 0, j = 0; i < n_q && j < n_t;) {
+            if (qmins[i] < g.mins[j]) i++;
+            else if (g.mins[j] < qmins[i]) j++;
+            else { shared.push_back((double)g.abunds[j]); i++; j++; }
+        }
+        if (shared.size() != isect[r])
+            throw IndexError(IndexError::Gpu, "search: a row's intersect does not match the sketches it was computed from");
+        std::sort(shared.begin(), shared.end());
+        const size_t n = shared.size();
+        double sum = 0;
+        for (double x : shared) sum += x;
+        const double mean = sum / (double)n;
+        double ss = 0;
+        for (double x : shared) ss += (x - mean) * (x - mean);
+        SearchResult o;
+        o.query_name = queries[q].second;
+        if (q_md5[q].empty()) q_md5[q] = sourmash_md5(qmins, n_q, ksize_);
+        o.query_md5 = q_md5[q];
+        o.match_name = g.name;
+        if (dev_md5_[t].empty()) dev_md5_[t] = sourmash_md5(g.mins.data(), n_t, ksize_);
+        o.match_md5 = dev_md5_[t];
+        o.moltype = moltype_;
+        o.intersect_hashes = isect[r];
+        o.ksize = ksize_ * PROTEIN_TO_MINHASH_RATIO;
+        o.scaled = scaled_;
+        const double I = (double)isect[r];
+        const double cq = I / (double)n_q, ct = I / (double)n_t;
+        o.containment = cq;
+        o.jaccard = I / (double)(n_q + n_t - isect[r]);
+        o.max_containment = std::max(cq, ct);
+        o.average_abund = mean;
+        o.median_abund = (n % 2) ? shared[n / 2] : (shared[n / 2 - 1] + shared[n / 2]) / 2.0;
+        o.std_abund = std::sqrt(ss / (double)n);
+        o.query_containment_ani = std::pow(cq, 1.0 / k3);
+        o.match_containment_ani = std::pow(ct, 1.0 / k3);
+        o.average_containment_ani = (o.query_containment_ani + o.match_containment_ani) / 2.0;
+        o.max_containment_ani = std::max(o.query_containment_ani, o.match_containment_ani);
+        o.n_weighted_found = nw[r];
+        o.total_weighted_hashes = dev_total_abund_[t];
+        o.containment_target_in_query = ct;
+        o.f_weighted_target_in_query = (double)nw[r] / (double)dev_total_abund_[t];
+        rows.push_back(std::move(o));
+    }
+    return rows;
+}
+
+std::vector<SearchResult> ProteomeIndex::search_fasta(const std::string &fasta_path, size_t batch_size) {
+    std::vector<SearchResult> rows;
+    for_each_fasta_batch(fasta_path, batch_size ? batch_size : 100000, 0,
+                         [&](std::vector<std::pair<std::string, std::string>> &batch) {
+                             std::vector<SearchResult> part = search(batch, true); // the FASTA path upper-cases (index.rs:1000)
+                             for (auto &r : part) rows.push_back(std::move(r));
+                         },
+                         nullptr);
+    return rows;
 }
 
 // ---- persistence: flat little-endian file (own format; RocksDB layout is out of scope) --------------------
@@ -616,6 +849,56 @@ int ksh_index_add_records(ksh_index *ix, const char *const *sequences, const cha
 int ksh_index_process_fasta(ksh_index *ix, const char *fasta_path, uint32_t progress_interval, uint64_t batch_size,
                             char *err, size_t err_cap) {
     KSH_GUARD(ix->ix->process_fasta(fasta_path, progress_interval, (size_t)batch_size))
+}
+
+static std::string json_rows(const std::vector<kmerseek::SearchResult> &rows) {
+    std::ostringstream o;
+    auto num = [&](double v) { char b[40]; snprintf(b, sizeof b, "%.17g", v); o << b; }; // (17 digits: the f64 round-trips)
+    o << "[";
+    for (size_t i = 0; i < rows.size(); i++) {
+        const kmerseek::SearchResult &r = rows[i];
+        o << (i ? "," : "") << "{\"query_name\":"; json_str(o, r.query_name);
+        o << ",\"query_md5\":"; json_str(o, r.query_md5);
+        o << ",\"match_name\":"; json_str(o, r.match_name);
+        o << ",\"containment\":"; num(r.containment);
+        o << ",\"intersect_hashes\":" << r.intersect_hashes << ",\"ksize\":" << r.ksize << ",\"scaled\":" << r.scaled;
+        o << ",\"moltype\":"; json_str(o, r.moltype);
+        o << ",\"match_md5\":"; json_str(o, r.match_md5);
+        o << ",\"jaccard\":"; num(r.jaccard);
+        o << ",\"max_containment\":"; num(r.max_containment);
+        o << ",\"average_abund\":"; num(r.average_abund);
+        o << ",\"median_abund\":"; num(r.median_abund);
+        o << ",\"std_abund\":"; num(r.std_abund);
+        o << ",\"query_containment_ani\":"; num(r.query_containment_ani);
+        o << ",\"match_containment_ani\":"; num(r.match_containment_ani);
+        o << ",\"average_containment_ani\":"; num(r.average_containment_ani);
+        o << ",\"max_containment_ani\":"; num(r.max_containment_ani);
+        o << ",\"n_weighted_found\":" << r.n_weighted_found << ",\"total_weighted_hashes\":" << r.total_weighted_hashes;
+        o << ",\"containment_target_in_query\":"; num(r.containment_target_in_query);
+        o << ",\"f_weighted_target_in_query\":"; num(r.f_weighted_target_in_query);
+        o << "}";
+    }
+    o << "]";
+    return o.str();
+}
+
+int ksh_index_search(ksh_index *ix, const char *const *sequences, const char *const *names, uint32_t n, int upper, char **json_out,
+                     char *err, size_t err_cap) {
+    KSH_GUARD({
+        if (!ix || !json_out || (n && (!sequences || !names))) throw IndexError(IndexError::ValidationError, "Validation error: NULL argument");
+        std::vector<std::pair<std::string, std::string>> recs(n);
+        for (uint32_t i = 0; i < n; i++) recs[i] = {sequences[i], names[i]};
+        *json_out = dup_string(json_rows(ix->ix->search(recs, upper != 0)));
+        if (!*json_out) throw std::bad_alloc();
+    })
+}
+
+int ksh_index_search_fasta(ksh_index *ix, const char *fasta_path, uint64_t batch_size, char **json_out, char *err, size_t err_cap) {
+    KSH_GUARD({
+        if (!ix || !json_out || !fasta_path) throw IndexError(IndexError::ValidationError, "Validation error: NULL argument");
+        *json_out = dup_string(json_rows(ix->ix->search_fasta(fasta_path, (size_t)batch_size)));
+        if (!*json_out) throw std::bad_alloc();
+    })
 }
 
 uint64_t ksh_index_signature_count(const ksh_index *ix) { return ix->ix->signature_count(); }

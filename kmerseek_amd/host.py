@@ -28,6 +28,9 @@ HOST_SIGNATURES = {
     "ksh_index_add_records": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint32, C.c_int,
                                         C.c_char_p, C.c_size_t]),
     "ksh_index_process_fasta": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint64, C.c_char_p, C.c_size_t]),
+    "ksh_index_search": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint32, C.c_int,
+                                   C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "ksh_index_search_fasta": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
     "ksh_index_signature_count": (C.c_uint64, [C.c_void_p]),
     "ksh_index_combined_minhash_size": (C.c_uint64, [C.c_void_p]),
     "ksh_index_ksize": (C.c_uint32, [C.c_void_p]),
@@ -211,6 +214,24 @@ class ProteomeIndex:
     def save_state(self) -> None:
         _call(self._L.ksh_index_save_state, self._h)
 
+    # -- search (added: SURVEY 8(b); the reference's crate has none — rows of branchwater manysearch,
+    #    src/python/kmerseek/search.py:125-141, for the signatures this index holds) -------------------------------------
+    def search(self, records: Sequence[Tuple[str, str]], upper: bool = False) -> List[dict]:
+        """(sequence, name) query records against the stored signatures: one dict per (query, match) pair that shares a
+        hash, keys = SEARCH_COLUMNS.  Queries are validated / resolved like create_protein_signature's input."""
+        n = len(records)
+        seqs = (C.c_char_p * n)(*[r[0].encode() for r in records])
+        names = (C.c_char_p * n)(*[r[1].encode() for r in records])
+        out = C.c_void_p()
+        _call(self._L.ksh_index_search, self._h, seqs, names, n, 1 if upper else 0, C.byref(out))
+        return json.loads(_take_string(self._L, out))
+
+    def search_fasta(self, fasta_path, batch_size: int = 100000) -> List[dict]:
+        """Every record of a FASTA file (plain / gzip / zstd / bzip2 / xz) as queries (upper-cased, as the FASTA path does)."""
+        out = C.c_void_p()
+        _call(self._L.ksh_index_search_fasta, self._h, str(fasta_path).encode(), batch_size, C.byref(out))
+        return json.loads(_take_string(self._L, out))
+
     # -- getters ------------------------------------------------------------------------------------
     def signature_count(self) -> int:
         return int(self._L.ksh_index_signature_count(self._h))
@@ -303,11 +324,63 @@ class ProteomeIndexBuilder:
         return self._build(1)
 
 
+# the 22 columns of a search row, in the reference's CSV order (tests/test_search.py:33-39)
+SEARCH_COLUMNS = [
+    "query_name", "query_md5", "match_name", "containment", "intersect_hashes", "ksize", "scaled", "moltype",
+    "match_md5", "jaccard", "max_containment", "average_abund", "median_abund", "std_abund",
+    "query_containment_ani", "match_containment_ani", "average_containment_ani", "max_containment_ani",
+    "n_weighted_found", "total_weighted_hashes", "containment_target_in_query", "f_weighted_target_in_query",
+]
+
+
+def write_search_csv(rows: List[dict], path) -> int:
+    """Rows of ProteomeIndex.search as the reference's manysearch CSV (same header, same column order)."""
+    import csv
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=SEARCH_COLUMNS, lineterminator="\n")
+        w.writeheader()
+        w.writerows(rows)
+    return len(rows)
+
+
 class PyProteomeIndex:
-    """src/rust/lib.rs:74-92: constructor only; any failure -> RuntimeError(str(e))."""
+    """src/rust/lib.rs:74-92: ``PyProteomeIndex(ksize, scaled, moltype, db_path)``, any failure -> RuntimeError(str(e)).
+    The reference's class stops at the constructor (lib.rs:76-79: the index it holds is "Not currently used"); the
+    ``sketch_*`` / ``search_*`` methods are the ones SURVEY 8(b) asks to add: sketch records into the index
+    (ProteomeIndex::process_fasta / create_protein_signature + store_signatures, index.rs:907-961, 719-830) and search
+    records against it (rows of src/python/kmerseek/search.py:125-141)."""
 
     def __init__(self, ksize: int, scaled: int, moltype, db_path: str):
         self.index = ProteomeIndex(db_path, ksize, scaled, str(moltype), False)
+
+    # -- sketch_*: records -> signatures stored in the index ------------------------------------------------------
+    def sketch_fasta(self, fasta_path, batch_size: int = 100000) -> int:
+        """process_fasta (index.rs:907-961): every record sketched and stored; returns the number of stored signatures."""
+        self.index.process_fasta(fasta_path, 0, batch_size)
+        return self.index.signature_count()
+
+    def sketch_sequences(self, records: Sequence[Tuple[str, str]]) -> int:
+        """(sequence, name) records sketched (one GPU batch) and stored; returns the number of stored signatures."""
+        self.index.add_records(list(records), upper=False)
+        return self.index.signature_count()
+
+    def signature_count(self) -> int:
+        return self.index.signature_count()
+
+    # -- search_*: records -> manysearch rows against the stored signatures --------------------------------------------
+    def search_fasta(self, fasta_path, output=None, batch_size: int = 100000) -> List[dict]:
+        """Every record of a FASTA file searched against the index; with `output` the rows are also written as the
+        reference's 22-column CSV."""
+        rows = self.index.search_fasta(fasta_path, batch_size)
+        if output is not None:
+            write_search_csv(rows, output)
+        return rows
+
+    def search_sequences(self, records: Sequence[Tuple[str, str]], output=None) -> List[dict]:
+        rows = self.index.search(list(records), upper=False)
+        if output is not None:
+            write_search_csv(rows, output)
+        return rows
 
 
 def sketch_fasta(path, ksize: int, scaled: int, moltype: str, validate: bool = False, device: int = 0,

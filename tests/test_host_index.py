@@ -188,6 +188,70 @@ def test_pyo3_surface(tmp_path):
         host.PyProteomeIndex(16, 5, "nope", str(tmp_path / "py2.db"))
 
 
+# SURVEY 8(b) "add sketch_* / search_*": the object API's search — BCL2-25 indexed through process_fasta, ced9 searched through
+# ProteomeIndex.search_fasta / PyProteomeIndex.search_fasta -> exactly the 5 x 22 expected rows of the reference's
+# tests/test_search.py:33-39 (src/python/kmerseek/search.py:125-141 over src/rust/index.rs:642-652)
+def _assert_rows_equal_expected(rows, search_expected):
+    got = sorted(rows, key=lambda r: r["match_name"])
+    exp = sorted(search_expected["manysearch_rows"], key=lambda r: r["match_name"])
+    assert len(got) == len(exp) == 5
+    assert list(got[0].keys()) == search_expected["manysearch_columns"] == host.SEARCH_COLUMNS
+    for g, w in zip(got, exp):
+        for col in search_expected["manysearch_columns"]:
+            if col in ("query_name", "query_md5", "match_name", "match_md5", "moltype"):
+                assert str(g[col]) == w[col], col
+            else:
+                assert math.isclose(float(g[col]), float(w[col]), rel_tol=1e-12, abs_tol=1e-15), (col, g[col], w[col])
+
+
+def test_proteome_index_search_equals_expected(tmp_path, search_expected):
+    ix = new_index(tmp_path, 16, 5, "hp")
+    ix.process_fasta(os.path.join(GOLDEN, BCL2), 0, 1000)
+    assert ix.signature_count() == 25
+    rows = ix.search_fasta(os.path.join(GOLDEN, "ced9.fasta"))
+    _assert_rows_equal_expected(rows, search_expected)
+    assert all(r["query_md5"] == "fe3714626e8180caf90f78091563aae6" for r in rows)
+    # the same through (sequence, name) records, and again: the device-resident index is built once and reused
+    name, seq = wire.read_fasta(os.path.join(GOLDEN, "ced9.fasta"))[0]
+    for _ in range(2):
+        _assert_rows_equal_expected(ix.search([(seq.decode(), name)]), search_expected)
+    # two queries in one batch: rows grouped by query, in batch order; a query that shares nothing has no rows
+    rows2 = ix.search([("ACDEFGHIK", "no_match"), (seq.decode(), name), (seq.decode().lower(), "lower")], upper=True)
+    assert [r["query_name"] for r in rows2] == [name] * 5 + ["lower"] * 5
+    _assert_rows_equal_expected(rows2[:5], search_expected)
+    # storing more signatures invalidates the device index: the next search sees them
+    ix.add_records([(seq.decode(), "ced9_copy")])
+    rows3 = ix.search([(seq.decode(), name)])
+    assert len(rows3) == 6
+    me = [r for r in rows3 if r["match_name"] == "ced9_copy"][0]
+    assert me["containment"] == 1.0 and me["jaccard"] == 1.0 and me["intersect_hashes"] == 49 and me["max_containment_ani"] == 1.0
+    assert me["match_md5"] == me["query_md5"]
+    # queries are validated like create_protein_signature's input: the reference's message, first bad record aborts
+    with pytest.raises(host.IndexError_) as e:
+        ix.search([(seq.decode(), name), ("PLANT1ANDANIMAL", "bad")])
+    assert "Invalid amino acid '1'" in str(e.value) and e.value.kind == "InvalidAminoAcid"
+    # an empty index, an empty batch
+    assert new_index(tmp_path, 16, 5, "hp", name="empty.db").search([(seq.decode(), name)]) == []
+    assert ix.search([]) == []
+
+
+def test_pyo3_sketch_and_search_methods(tmp_path, search_expected):
+    p = host.PyProteomeIndex(16, 5, host.PyProteinEncoding.hp(), str(tmp_path / "py.db"))
+    assert p.sketch_fasta(os.path.join(GOLDEN, BCL2)) == 25 == p.signature_count()
+    out = tmp_path / "search.csv"
+    rows = p.search_fasta(os.path.join(GOLDEN, "ced9.fasta"), output=str(out))
+    _assert_rows_equal_expected(rows, search_expected)
+    back = list(csv.DictReader(open(out)))
+    assert list(back[0].keys()) == search_expected["manysearch_columns"]
+    _assert_rows_equal_expected(back, search_expected)
+    # sketch_sequences / search_sequences on records
+    q = host.PyProteomeIndex(5, 1, "protein", str(tmp_path / "py2.db"))
+    assert q.sketch_sequences([(TEST_PROTEIN, "a"), ("LIVINGALIVE", "b")]) == 2
+    rows = q.search_sequences([("PLANTANDANIMAL", "q")])
+    assert len(rows) == 1 and rows[0]["match_name"] == "a" and rows[0]["intersect_hashes"] == 10 and rows[0]["containment"] == 1.0
+    assert rows[0]["ksize"] == 15 and rows[0]["scaled"] == 1 and rows[0]["moltype"] == "protein"
+
+
 # tests/test_entity.py:9-22 (the sketch artifact equals the committed golden .sig.zip)
 @pytest.mark.parametrize("key,ksize", [("hp.k24.scaled5", 24), ("hp.k16.scaled5", 16), ("hp.k15.scaled5", 15)])
 def test_sketch_sig_zip_equals_golden(tmp_path, golden_sketches, key, ksize):
