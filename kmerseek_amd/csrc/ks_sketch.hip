@@ -263,6 +263,25 @@ KS_DEV u32 sk_place_window(const sk_args &A, u32 p, u64 h, sk_seq &q, const sk_b
     return bo;
 }
 
+// The same for k >= SK_E, branch-free in the sequence: a sequence's last k - 1 positions start no window, so the SK_E
+// consecutive positions of a thread hold windows of at most ONE sequence — the first whose last window lies at or beyond the
+// thread's first position (found once per thread: the binary search of phase 2 with key q0 + k - 1) — and a position p
+// starts a real window of it iff (p - ls) < nw, unsigned.  No per-window walk over the boundaries, no per-window sequence
+// code (round 3: a compare + branch + three range tests per window, 25 vector + 14 scalar instructions of bookkeeping per
+// window against 66 of hashing; profiles/r03_sq_counters.md).  `thr`: the keep-below-threshold test (scaled > 1 only).
+KS_DEV u32 sk_place_window_run(u32 p, u64 h, u32 ls, u32 nw, u32 mul, u32 s24, bool thr, u64 max_hash, u32 *cnt) {
+    bool keep = (p - ls) < nw && h != 0;
+    if (thr) keep = keep && h <= max_hash;
+    u32 bo = 0xffffffffu;
+    if (keep) {
+        const u32 b = ls + __umulhi((u32)(h >> 32), mul);
+        const u32 sh = b << 4; // (only bits [4:0] of a shift amount / bit-field offset count: (b & 1) * 16)
+        const u32 o = __builtin_amdgcn_ubfe(atomicAdd(&cnt[b >> 1], 1u << (sh & 31u)), sh, 16u); // two 16-bit counters per word
+        bo = s24 | (b << 12) | o; // b, o < 4096
+    }
+    return bo;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Packed tiles (plain variant, scaled = 1): instead of cutting the batch at fixed residue strides — where a stride of 3312
 // leaves 19 % of a tile's 4096 positions empty so that few sequences straddle a tile's end — tiles are packed greedily
@@ -351,13 +370,21 @@ KS_DEV void sk_cmp_half(const sk_args &A, const sk_bounds &B, sk_seq &q, const u
         h[1] = sk_hash_window<H + 1, KC>(wl, A.k, A.seed);
         h[2] = sk_hash_window<H + 2, KC>(wl, A.k, A.seed);
         h[3] = sk_hash_window<H + 3, KC>(wl, A.k, A.seed);
+        if ((KC ? (u32)KC : A.k) >= SK_E) { // (uniform) one sequence per thread: sk_place_window_run
+            const u32 srel = q.s - s_first;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const u32 p = p0 + H + i;
-            while (q.s < s_end && p >= q.le) { q.s++; sk_load_seq(q, A, B, s_end); }
-            if (q.ok && p >= q.ls && p + A.k <= q.le && h[i] != 0 && h[i] <= A.max_hash) {
-                keep |= 1u << i;
-                sr |= (q.s - s_first) << (8 * i);
+            for (int i = 0; i < 4; i++)
+                if ((p0 + H + i - q.ls) < q.nw && h[i] != 0 && h[i] <= A.max_hash) keep |= 1u << i;
+            sr = srel * 0x01010101u;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u32 p = p0 + H + i;
+                while (q.s < s_end && p >= q.le) { q.s++; sk_load_seq(q, A, B, s_end); }
+                if (q.ok && p >= q.ls && p + A.k <= q.le && h[i] != 0 && h[i] <= A.max_hash) {
+                    keep |= 1u << i;
+                    sr |= (q.s - s_first) << (8 * i);
+                }
             }
         }
     }
@@ -510,12 +537,15 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     // ---- phase 2: hash 8 consecutive windows per thread, bucket + arrival slot via LDS atomics
     const u32 q0 = tid * SK_E;
     sk_seq q;
+    const u32 kk = KC ? (u32)KC : A.k;
+    const bool onerun = kk >= SK_E; // (uniform; compile-time for the folded k-mer sizes) see sk_place_window_run
     {
-        // first sequence of the tile whose end lies beyond q0
+        // first sequence of the tile whose end lies beyond q0 — whose LAST WINDOW lies at or beyond q0 when k >= SK_E
+        const u32 key = onerun ? q0 + kk - 1u : q0;
         u32 lo = s_first, hi = s_end;
         while (lo < hi) {
             u32 mid = lo + ((hi - lo) >> 1);
-            if (B.at(mid + 1) > q0) hi = mid; else lo = mid + 1;
+            if (B.at(mid + 1) > key) hi = mid; else lo = mid + 1;
         }
         q.s = lo;
         sk_load_seq(q, A, B, s_end);
@@ -524,7 +554,11 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     u64 h[SK_E];
     u32 bo[SK_E];
     // (uniform) postings are wanted and this variant ranks them while it hashes (the compacting variant keeps the later pass)
+#ifdef SK_NO_EARLY // (diagnostic builds only)
+    const bool early = false;
+#else
     const bool early = !CMP && A.part_keys != nullptr && B.in_lds;
+#endif
     u32 rkp[SK_E / 2] = {0, 0, 0, 0}; // ranks inside (tile, digit) of my windows, 16 bits each
     if (CMP) {
         // ---- phase 2, compacting variant: hash sub-tile by sub-tile, keep the windows under the threshold in an LDS list
@@ -543,11 +577,12 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                 rv = load_chunk((u64)tile * A.R + (u64)(sub + 1) * SK_TILE + (u64)tid * 16);
             const u32 p0 = sub * SK_TILE + q0;
             const bool active = p0 < end_l;
-            if (active) { // the sequence that holds (or follows) position p0
+            if (active) { // the sequence that holds (or follows) position p0 — whose last window lies at or beyond it when k >= SK_E
+                const u32 key = onerun ? p0 + kk - 1u : p0;
                 u32 lo = s_first, hi = s_end;
                 while (lo < hi) {
                     u32 mid = lo + ((hi - lo) >> 1);
-                    if (B.at(mid + 1) > p0) hi = mid; else lo = mid + 1;
+                    if (B.at(mid + 1) > key) hi = mid; else lo = mid + 1;
                 }
                 q.s = lo;
                 sk_load_seq(q, A, B, s_end);
@@ -612,8 +647,16 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         h[5] = sk_hash_window<5, KC>(wl, A.k, A.seed);
         h[6] = sk_hash_window<6, KC>(wl, A.k, A.seed);
         h[7] = sk_hash_window<7, KC>(wl, A.k, A.seed);
+        if (onerun) {
+            const u32 srel = q.s - B.s_first;
+            const u32 s24 = (srel < 254u ? srel : 254u) << 24;
+            const bool thr = A.max_hash != ~0ULL; // (uniform)
 #pragma unroll
-        for (int i = 0; i < SK_E; i++) bo[i] = sk_place_window(A, q0 + i, h[i], q, B, s_end, cnt);
+            for (int i = 0; i < SK_E; i++) bo[i] = sk_place_window_run(q0 + i, h[i], q.ls, q.nw, q.mul, s24, thr, A.max_hash, cnt);
+        } else {
+#pragma unroll
+            for (int i = 0; i < SK_E; i++) bo[i] = sk_place_window(A, q0 + i, h[i], q, B, s_end, cnt);
+        }
         // Postings (query side): a kept hash's rank inside its partition digit is one more LDS atomic — taken HERE, while the
         // vector ALU is what the workgroup waits for and the LDS idles.  A tile without repeats (nearly all) then emits its
         // postings straight from these window-order registers: no sequence lookup, no counting phase of its own.
@@ -1154,10 +1197,14 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         for (u32 d = tid; d < n_distinct; d += SK_THREADS) {
             u64 pos = base + d;
             for (u32 e = 0; e < ne; e++) pos += ext_d[e] <= d ? ext_cnt[e] : 0;
+#ifdef SK_NO_CSR_STORES // (diagnostic builds only: the kernel's time without the CSR stores)
+            if (pos == 0xffffffffffffULL) A.out_abund[0] = (u32)tmp[d];
+#else
             if (pos < A.out_cap) { // (capacity-bounded output: the host sees the true total in csr[n_seqs] and repeats larger)
                 A.out_hash[pos] = tmp[d];
                 A.out_abund[pos] = any_dup ? (u32)abund_s[d] : 1u;
             }
+#endif
         }
     }
     if (A.part_keys && !B.in_lds) { // sequence ids do not fit the element code: let the host repartition this batch
