@@ -68,6 +68,48 @@ extern "C" int ks_sketch_batch(ks_ctx *ctx, const uint8_t *residues, const uint6
     });
 }
 
+// ---- slots -> plain CSR --------------------------------------------------------------------------------------------------
+// A sketch call leaves every sequence a slot as long as its KEPT hashes (ks_common.h: ks_sketches); where a sequence repeats a
+// k-mer its distinct hashes fill only the head of the slot.  One gather (one wave per sequence) closes the gaps: new offsets =
+// exclusive scan of the distinct counts.  Only batches with repeats pay for it, and only when something reads the arrays as a
+// plain CSR (copies to the host, the device accessors of the ABI, an index build, a search that starts from the CSR, a union).
+__global__ __launch_bounds__(256) void k_dense_gather(const u64 *old_offs, const u64 *new_offs, const u64 *oh, const u32 *oa, u32 n_seqs,
+                                                      u64 *nh, u32 *na) {
+    const u32 s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_seqs) return;
+    const u64 src = old_offs[s], dst = new_offs[s], n = new_offs[s + 1] - dst;
+    for (u64 j = threadIdx.x & 63; j < n; j += 64) { nh[dst + j] = oh[src + j]; na[dst + j] = oa[src + j]; }
+}
+
+int ks_sketches_make_dense(ks_ctx *ctx, ks_sketches *S) {
+    if (!S || !S->gapped) return KS_OK;
+    if (S->pending) return ks_fail(ctx, KS_ERR_INVALID_ARG, "sketches with a pending read-back cannot be made dense");
+    if (!S->d_counts) return ks_fail(ctx, KS_ERR_HIP, "internal error: gapped sketches without per-sequence counts");
+    KS_HIP(ctx, hipSetDevice(ctx->device));
+    u64 *no = nullptr, *nh = nullptr;
+    u32 *na = nullptr;
+    int st = ks_alloc(ctx, &no, (size_t)S->n_seqs + 1);
+    if (st == KS_OK) st = ks_alloc(ctx, &nh, (size_t)S->n_hashes);
+    if (st == KS_OK) st = ks_alloc(ctx, &na, (size_t)S->n_hashes);
+    if (st == KS_OK) st = ks_scan_u32_to_u64(ctx, S->d_counts, no, S->n_seqs);
+    if (st == KS_OK && S->n_seqs) {
+        ks_timer_begin(ctx, "dense_gather");
+        hipLaunchKernelGGL(k_dense_gather, dim3((S->n_seqs + 3) / 4), dim3(256), 0, ctx->stream, (const u64 *)S->d_offsets, (const u64 *)no,
+                           (const u64 *)S->d_hashes, (const u32 *)S->d_abunds, S->n_seqs, nh, na);
+        ks_timer_end(ctx);
+        if (hipGetLastError() != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "dense gather launch failed");
+    }
+    if (st == KS_OK) st = ks_scan_status_fetch(ctx);
+    if (st == KS_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = ks_fail(ctx, KS_ERR_HIP, "dense gather failed");
+    if (st == KS_OK) st = ks_scan_status_check(ctx);
+    if (st != KS_OK) { ks_pool_free(ctx, no); ks_pool_free(ctx, nh); ks_pool_free(ctx, na); return st; }
+    ks_pool_free(ctx, S->d_offsets); ks_pool_free(ctx, S->d_hashes); ks_pool_free(ctx, S->d_abunds);
+    S->d_offsets = no; S->d_hashes = nh; S->d_abunds = na;
+    S->n_slots = S->n_hashes;
+    S->gapped = false;
+    return KS_OK;
+}
+
 extern "C" uint32_t ks_sketches_n_seqs(const ks_sketches *s) { return s ? s->n_seqs : 0; }
 extern "C" uint64_t ks_sketches_n_hashes(const ks_sketches *s) { return s ? s->n_hashes : 0; }
 extern "C" uint64_t ks_sketches_n_windows(const ks_sketches *s) { return s ? s->n_windows : 0; }
@@ -76,15 +118,23 @@ extern "C" int ks_sketches_has_postings(const ks_sketches *s) {
     });
 }
 extern "C" void ks_sketches_params(const ks_sketches *s, ks_params *out) { if (s && out) *out = s->params; }
-extern "C" const uint64_t *ks_sketches_device_offsets(const ks_sketches *s) { return s ? s->d_offsets : nullptr; }
-extern "C" const uint64_t *ks_sketches_device_hashes(const ks_sketches *s) { return s ? s->d_hashes : nullptr; }
-extern "C" const uint32_t *ks_sketches_device_abunds(const ks_sketches *s) { return s ? s->d_abunds : nullptr; }
+// (the arrays the ABI shows are a plain CSR: a batch whose slots have gaps is made dense on first sight — the object is
+// logically const: same sketches — and NULL comes back if that fails, with the reason in ks_last_error)
+static const ks_sketches *dense_view(const ks_sketches *s) {
+    if (!s || !s->gapped) return s;
+    ks_sketches *m = const_cast<ks_sketches *>(s);
+    return ks_guard(m->ctx, [&]() -> int { return ks_sketches_make_dense(m->ctx, m); }) == KS_OK ? s : nullptr;
+}
+extern "C" const uint64_t *ks_sketches_device_offsets(const ks_sketches *s) { s = dense_view(s); return s ? s->d_offsets : nullptr; }
+extern "C" const uint64_t *ks_sketches_device_hashes(const ks_sketches *s) { s = dense_view(s); return s ? s->d_hashes : nullptr; }
+extern "C" const uint32_t *ks_sketches_device_abunds(const ks_sketches *s) { s = dense_view(s); return s ? s->d_abunds : nullptr; }
 
 extern "C" int ks_sketches_copy_to_host(ks_ctx *ctx, const ks_sketches *s, uint64_t *offsets, uint64_t *hashes,
                                         uint32_t *abunds) {
     return ks_guard(ctx, [&]() -> int {
     if (!ctx || !s) return KS_ERR_INVALID_ARG;
     KS_HIP(ctx, hipSetDevice(ctx->device));
+    KS_TRY(ks_sketches_make_dense(ctx, const_cast<ks_sketches *>(s)));
     if (offsets) KS_HIP(ctx, hipMemcpyAsync(offsets, s->d_offsets, ((size_t)s->n_seqs + 1) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     if (hashes && s->n_hashes) KS_TRY(ks_copy_d2h(ctx, hashes, s->d_hashes, (size_t)s->n_hashes * sizeof(u64)));
     if (abunds && s->n_hashes) KS_TRY(ks_copy_d2h(ctx, abunds, s->d_abunds, (size_t)s->n_hashes * sizeof(u32)));
@@ -118,7 +168,7 @@ extern "C" int ks_sketches_from_host(ks_ctx *ctx, const uint64_t *offsets, const
     KS_HIP(ctx, hipSetDevice(ctx->device));
     ks_sketches *S = new ks_sketches();
     memset(S, 0, sizeof *S);
-    S->ctx = ctx; S->params = *params; S->n_seqs = n_seqs; S->n_hashes = n; S->n_windows = 0;
+    S->ctx = ctx; S->params = *params; S->n_seqs = n_seqs; S->n_hashes = S->n_slots = n; S->n_windows = 0;
     int st = ks_alloc(ctx, &S->d_offsets, (size_t)n_seqs + 1);
     if (st == KS_OK) st = ks_alloc(ctx, &S->d_hashes, (size_t)n);
     if (st == KS_OK) st = ks_alloc(ctx, &S->d_abunds, (size_t)n);
@@ -145,6 +195,7 @@ extern "C" void ks_sketches_free(ks_sketches *s) {
     ks_pool_free(s->ctx, s->d_offsets);
     ks_pool_free(s->ctx, s->d_hashes);
     ks_pool_free(s->ctx, s->d_abunds);
+    ks_pool_free(s->ctx, s->d_counts);
     ks_pool_free(s->ctx, s->part_keys);
     ks_pool_free(s->ctx, s->part_vals);
     if (s->ctl_block) ks_pool_free(s->ctx, s->ctl_block); // (part_len lies inside it)

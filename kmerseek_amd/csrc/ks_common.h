@@ -190,9 +190,18 @@ struct ks_sketches {
     u32 n_seqs;
     u64 n_hashes;
     u64 n_windows;
+    // CSR with slots: d_offsets[s] is where sequence s's SLOT starts — as long as the sequence's kept hashes, repeats included,
+    // so that a tile knows its place as soon as it has hashed (ks_sketch.hip: the look-back runs on kept counts) — and the
+    // sequence's sketch (ascending distinct hashes + abundances) is the first d_counts[s] entries of the slot.  gapped == false
+    // (no sequence repeats a k-mer: every synthetic batch, most real ones at large k; or after ks_sketches_make_dense): slots and
+    // runs coincide and d_offsets is the plain CSR of the C ABI.  Everything that reads the arrays as a plain CSR calls
+    // ks_sketches_make_dense first (one gather pass, only when gapped); the fused postings of a query batch never do.
     u64 *d_offsets; // n_seqs + 1
-    u64 *d_hashes;  // n_hashes
-    u32 *d_abunds;  // n_hashes
+    u64 *d_hashes;  // n_slots
+    u32 *d_abunds;  // n_slots
+    u32 *d_counts;  // n_seqs distinct hashes per sequence, or NULL (sketches from host arrays, unions: dense by construction)
+    u64 n_slots;    // d_offsets[n_seqs]
+    bool gapped;
     // optional, made by ks_sketch_queries_device: postings (hash, seq) already partitioned on hash bits
     // low 8 bits of the join prefix (ks_join_prefix) into part_regions fixed-capacity regions (region r holds part_len[r] records
     // starting at r * part_cap) — the first partition pass of a search against an index that joins on part_pbits bits
@@ -358,6 +367,8 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
 int ks_union_impl(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out);
 
 int ks_check_params(ks_ctx *ctx, const ks_params *p);
+// gapped slots -> plain CSR (see ks_sketches); no-op for dense sketches.  Enqueued on ctx's stream.
+int ks_sketches_make_dense(ks_ctx *ctx, ks_sketches *s);
 
 // ---- boundary copies (ks_copy.hip): one DMA for pinned host memory, double-buffered pinned staging + copy threads otherwise
 int ks_copy_h2d(ks_ctx *ctx, void *dst_device, const void *src_host, size_t bytes); // enqueued; complete for pageable sources

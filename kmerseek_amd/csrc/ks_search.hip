@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void k_index_bmeta(const u64 *keys, const u64 
 int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
     if (!t || !out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     KS_HIP(ctx, hipSetDevice(ctx->device));
+    KS_TRY(ks_sketches_make_dense(ctx, const_cast<ks_sketches *>(t))); // (the sort reads the hashes as one dense array)
     ks_index *ix = new ks_index();
     memset(ix, 0, sizeof *ix);
     ix->ctx = ctx;
@@ -1321,6 +1322,7 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 ks_timer_end(ctx);
                 q_lo = dir_q; q_hi = dir_q + n_buckets;
             } else {
+                if (!pre) SE_CHECK(ks_sketches_make_dense(ctx, const_cast<ks_sketches *>(q))); // (this partition starts from the CSR)
                 SE_CHECK(ks_alloc(ctx, &qk0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qk1, (size_t)n_q));
                 SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_q)); SE_CHECK(ks_alloc(ctx, &qv1, (size_t)n_q));
                 if (pre) {
@@ -1600,6 +1602,7 @@ int ks_search_impl(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks_hit
     u64 need = 0;
     int st = search_core(ctx, ix, q, out, &need, sketch_redo);
     if (st != KS_OK || need == 0) return st;
+    KS_TRY(ks_sketches_make_dense(ctx, const_cast<ks_sketches *>(q))); // (a slice is a view of the batch's plain CSR)
     // ---- slices of roughly equal posting counts, each expected to produce KS_PAIR_LIMIT / 4 records
     std::vector<u64> offs((size_t)q->n_seqs + 1);
     KS_HIP(ctx, hipMemcpyAsync(offs.data(), q->d_offsets, offs.size() * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
@@ -1684,6 +1687,7 @@ __global__ __launch_bounds__(256) void k_union_emit(const u64 *keys, const u32 *
 int ks_union_impl(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out) {
     if (!in || !out) return ks_fail(ctx, KS_ERR_INVALID_ARG, "NULL argument");
     KS_HIP(ctx, hipSetDevice(ctx->device));
+    KS_TRY(ks_sketches_make_dense(ctx, const_cast<ks_sketches *>(in)));
     ks_sketches *U = new ks_sketches();
     memset(U, 0, sizeof *U);
     U->ctx = ctx; U->params = in->params; U->n_seqs = 1; U->n_windows = in->n_windows;
@@ -1717,7 +1721,7 @@ int ks_union_impl(ks_ctx *ctx, const ks_sketches *in, ks_sketches **out) {
         UN_HIP(hipMemcpyAsync(ctx->h_pin, d_nrows, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
         UN_HIP(hipStreamSynchronize(ctx->stream));
         const u32 n_rows = *(u32 *)ctx->h_pin;
-        U->n_hashes = n_rows;
+        U->n_hashes = U->n_slots = n_rows;
         UN_CHECK(ks_alloc(ctx, &row_start, (size_t)n_rows + 1));
         UN_CHECK(ks_alloc(ctx, &U->d_hashes, (size_t)n_rows)); UN_CHECK(ks_alloc(ctx, &U->d_abunds, (size_t)n_rows));
         ks_timer_begin(ctx, "pair_rows");

@@ -103,7 +103,10 @@ struct sk_args {
     u32 *out_abund;
     u64 *csr;       // [n_seqs + 1] final CSR offsets (MODE 0)
     u64 *total_out; // MODE 0: the batch's kept-hash total once more, next to the other words the host reads back
-    u32 *counts;    // [n_seqs] unique hashes of medium / long sequences (written by MODE 1 / k_sketch_long, read by MODE 0)
+    u32 *counts;    // [n_seqs] DISTINCT hashes of every sequence (ks_sketches::d_counts): written by whoever sketches the sequence
+    u32 *kept;      // [n_seqs] kept hashes (repeats included) of medium / long sequences (written by MODE 1 / k_sketch_long, read by
+                    // MODE 0: a deferred sequence's slot in the CSR is as long as its kept count)
+    u64 *drops_out; // kept hashes that repeat an earlier one of their sequence, summed over the batch (slots the CSR leaves empty)
     // decoupled look-back across tiles (MODE 0)
     unsigned long long *tile_status; // [n_tiles] (flag << 62) | value; flag 1 = tile aggregate, 2 = inclusive prefix
     u32 *ticket;    // [0] dynamic tile id, [1] status bits: 1 = a bounded spin expired, 2 = postings not emitted for some tile,
@@ -419,7 +422,8 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     static_assert(!(CMP && MODE), "the compacting variant is for shared tiles");
     __shared__ __attribute__((aligned(16))) u64 res_w[(SK_TILE + SK_PAD) / 8];
     __shared__ __attribute__((aligned(16))) u32 cnt[SK_TILE / 2 + 4]; // bucket counts, then starts: 16 bits each
-    __shared__ __attribute__((aligned(8))) u16 dseq[SK_SEQ_CAP + 2];                               // distinct rank at each sequence start
+    __shared__ __attribute__((aligned(8))) u16 dseq[SK_SEQ_CAP + 2];                               // sorted position (kept rank) at each sequence start
+    __shared__ u16 dsd[SK_SEQ_CAP + 2];                                                            // tiles with repeats: distinct rank there
     __shared__ __attribute__((aligned(16))) u64 tmp[SK_TILE];
     __shared__ u32 flagbits[SK_NFLAG];
     __shared__ u32 flagpre[SK_NFLAG + 1];
@@ -673,6 +677,16 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     __syncthreads();
 
     SK_STAMP_AT(2);
+    if (MODE == 0) { // a deferred (medium / long) sequence that starts inside this tile (at most one: the last): the length of its
+                     // CSR slot — its kept count — is known from the earlier launches (visible behind phase 3's barrier)
+        for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
+            const u32 ls = B.at(s), le = B.at(s + 1);
+            if (le > A.le_cap || le - ls > A.max_len_tile) {
+                const u32 e = atomicAdd(&ext_n, 1u);
+                if (e < 4) { ext_seq[e] = s; ext_cnt[e] = A.kept[s]; ext_d[e] = 0; }
+            }
+        }
+    }
     // ---- phase 3: bucket counts -> bucket starts (exclusive scan over the tile).  The thread that scans a bucket knows its
     // size: buckets that hold more than one hash are LISTED here and put in order in place by phase 5 — nothing is ranked
     // element by element (that cost as much as hashing: 812 VALU instructions per wave against 796, profiles/r02_sq_counters.md).
@@ -739,6 +753,17 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     // (the packed 16-bit starts read as a u16 array: one ds_read_u16 instead of read + shift + mask)
     auto bstart = [&](u32 b) -> u32 { return ((const u16 *)cnt)[b]; };
     const u32 n_kept = bstart(SK_TILE);
+    // ---- decoupled look-back, step 1 (MODE 0): publish this tile's aggregate — HERE, half a tile's life before its own look-back.
+    // The aggregate is the tile's KEPT count (repeats included), not its distinct count: the CSR gives every sequence a slot as
+    // long as its kept hashes and the distinct ones fill its head (ks_sketches::d_counts says how many; slots only differ from
+    // runs where a sequence repeats a k-mer).  The distinct count is known after the sort (phase 5), the kept count after the
+    // hash: a successor that arrives at its look-back finds aggregates published microseconds ago instead of waiting for
+    // its neighbours' sorts (round 3: -DSK_NO_LOOKBACK took 0.59 ms off a 2.11 ms launch, 0.17 ms off one that emits postings).
+    const u32 ne = MODE == 0 ? (ext_n < 4 ? ext_n : 4) : 0;
+    u64 agg = n_kept;
+    for (u32 e = 0; e < ne; e++) agg += ext_cnt[e];
+    if (MODE == 0 && tid == 0 && tile != A.debug_skip_tile)
+        __hip_atomic_store(&A.tile_status[tile], (tile == 0 ? SK_FLAG_PRE : SK_FLAG_AGG) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     SK_STAMP_AT(3);
     // ---- phase 4: scatter kept hashes into bucket order; sorted position at which every sequence's run starts
@@ -753,15 +778,6 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             const u32 ls = B.at(s);
             const u32 d = ls <= SK_TILE ? bstart(ls) : n_kept;
             if (d < n_kept) atomicOr(&flagbits[d >> 5], 1u << (d & 31));
-        }
-    }
-    if (MODE == 0) { // a deferred (medium / long) sequence that starts inside this tile (at most one: the last): its unique count is known
-        for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
-            const u32 ls = B.at(s), le = B.at(s + 1);
-            if (le > A.le_cap || le - ls > A.max_len_tile) {
-                const u32 e = atomicAdd(&ext_n, 1u);
-                if (e < 4) { ext_seq[e] = s; ext_cnt[e] = A.counts[s]; ext_d[e] = 0; }
-            }
         }
     }
     __syncthreads();
@@ -843,15 +859,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     const bool any_dup = n_rep != 0;   // (uniform)
     const u32 n_distinct = n_kept - n_rep;
     const bool posts = A.part_keys != nullptr && B.in_lds; // (uniform)
-    // ---- decoupled look-back, step 1 (MODE 0): publish this tile's aggregate as early as possible — a successor's look-back
-    // waits for it (0.5 ms of a 2.5 ms launch went to that wait when the aggregate was only published after phase 6).
-    // A deferred (medium / long) sequence that starts inside this tile (noted in phase 4) brings its unique count from the
-    // earlier launches into the aggregate.
-    const u32 ne = MODE == 0 ? (ext_n < 4 ? ext_n : 4) : 0;
-    u64 agg = n_distinct;
-    for (u32 e = 0; e < ne; e++) agg += ext_cnt[e];
-    if (MODE == 0 && tid == 0 && tile != A.debug_skip_tile)
-        __hip_atomic_store(&A.tile_status[tile], (tile == 0 ? SK_FLAG_PRE : SK_FLAG_AGG) | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && n_rep) atomicAdd((unsigned long long *)A.drops_out, (unsigned long long)n_rep); // slots the CSR leaves empty
 
     SK_STAMP_AT(5);
     // ---- phase 6 (tiles with repeats, tiles that emit postings): every thread takes 8 consecutive SORTED positions back into
@@ -1081,7 +1089,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     };
 
     if (MODE == 1) {
-        if (tid == 0) A.counts[s_first] = n_distinct;
+        if (tid == 0) { A.counts[s_first] = n_distinct; A.kept[s_first] = n_kept; }
         SK_STAMP_AT(6);
         if (any_dup) { // (the sorted run itself otherwise)
             stage_reps();
@@ -1104,14 +1112,9 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         // unique phases.  What does not need the tile's CSR base goes HERE, between publication and look-back: the posting
         // slices, the distinct rank of every sequence start, the staging of a tile with repeats.
         if (posts) post_offsets();
-        if (B.in_lds && (any_dup || ne)) // distinct rank at every sequence start (tiles without repeats: dseq as it stands)
-            for (u32 i = tid; i < ns; i += SK_THREADS) {
-                const u32 d0 = drank(dseq[i]);
-                for (u32 e = 0; e < ne; e++)
-                    if (ext_seq[e] == s_first + i) ext_d[e] = d0;
-                if (any_dup) dseq[i] = (u16)d0; // (own entry; the walks of phase 6 are done)
-            }
-        if (!B.in_lds && tid < ne) ext_d[tid] = drank(bstart(B.at(ext_seq[tid])));
+        if (B.in_lds && any_dup) // distinct rank at every sequence start (dseq keeps the kept ranks: they place the slots)
+            for (u32 i = tid; i <= ns; i += SK_THREADS) dsd[i] = (u16)drank(dseq[i]);
+        if (tid < ne) ext_d[tid] = B.in_lds ? (u32)dseq[ext_seq[tid] - s_first] : bstart(B.at(ext_seq[tid])); // kept rank at which the deferred sequence's slot opens
         if (posts) { // the postings leave first: their digit order goes through tmp, the sorted run is staged again behind them
             __syncthreads();
             post_emit();
@@ -1180,23 +1183,59 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         }
         const u64 base = excl;
         // final CSR offsets of every sequence that starts in this tile
+        // kept rank at the local position p (sequences of a tile that does not hold its boundaries in LDS)
+        auto krank = [&](u32 p) -> u32 { return bstart(p < SK_TILE ? p : SK_TILE); };
         for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
-            u64 pos = base + (B.in_lds ? (u32)dseq[s - s_first] : drank(bstart(B.at(s))));
+            const u32 i = s - s_first;
+            const u32 ls = B.at(s), le = B.at(s + 1);
+            u64 pos = base + (B.in_lds ? (u32)dseq[i] : krank(ls));
             for (u32 e = 0; e < ne; e++) pos += ext_seq[e] < s ? ext_cnt[e] : 0;
-            A.csr[s] = pos;
+            A.csr[s] = pos; // where the sequence's slot starts; its first counts[s] entries are its sketch
+            if (!(le > A.le_cap || le - ls > A.max_len_tile)) { // (a deferred sequence's count came from its own launch)
+                u32 c;
+                if (B.in_lds) c = any_dup ? (u32)dsd[i + 1] - (u32)dsd[i] : (u32)dseq[i + 1] - (u32)dseq[i];
+                else c = any_dup ? drank(krank(le)) - drank(krank(ls)) : krank(le) - krank(ls);
+                A.counts[s] = c;
+            }
         }
         if (s_end == A.n_seqs && tid == 0) { A.csr[A.n_seqs] = base + agg; *A.total_out = base + agg; }
-        if (!B.in_lds && any_dup) { // rare: more sequences than the LDS table holds, so the starts were needed until here
-            __syncthreads();
-            stage_reps();
-            __syncthreads();
+        if (!B.in_lds && any_dup) {
+            // Rare twice over: more sequences than the LDS tables hold (peptides) AND repeats.  No tables to look a representative's
+            // sequence up in, so the run leaves sequence by sequence: one thread walks a sequence's kept positions in tmp (sorted,
+            // repeats still in place; flagbits = representative flags, bucket starts still alive) and writes the representatives to
+            // the head of the sequence's slot, each with the length of its run as its abundance.
+            for (u32 s = s_first + tid; s < s_end; s += SK_THREADS) {
+                const u32 ls = B.at(s), le = B.at(s + 1);
+                if (le > A.le_cap || le - ls > A.max_len_tile) continue;
+                u64 pos = base + krank(ls);
+                for (u32 e = 0; e < ne; e++) pos += ext_seq[e] < s ? ext_cnt[e] : 0;
+                const u32 b = krank(ls), e2 = krank(le);
+                for (u32 p = b; p < e2;) { // (p holds a representative: the first position of a sequence always does)
+                    u32 q = p + 1;
+                    while (q < e2 && !((flagbits[q >> 5] >> (q & 31u)) & 1u)) q++;
+                    if (pos < A.out_cap) { A.out_hash[pos] = tmp[p]; A.out_abund[pos] = q - p; }
+                    pos++;
+                    p = q;
+                }
+            }
         }
         SK_STAMP_AT(7);
         // ---- phase 8: coalesced write-out straight into the final CSR arrays (runs of medium / long neighbours
         // leave gaps that k_place_long fills)
-        for (u32 d = tid; d < n_distinct; d += SK_THREADS) {
+        for (u32 d = tid; d < ((!B.in_lds && any_dup) ? 0u : n_distinct); d += SK_THREADS) {
             u64 pos = base + d;
-            for (u32 e = 0; e < ne; e++) pos += ext_d[e] <= d ? ext_cnt[e] : 0;
+            if (!any_dup) { // (uniform) distinct rank == kept rank: the run leaves as it lies
+                for (u32 e = 0; e < ne; e++) pos += ext_d[e] <= d ? ext_cnt[e] : 0;
+            } else {
+                // the representative with distinct rank d sits in the slot of its sequence: the last one whose distinct start is <= d
+                u32 lo = 0, hi = ns; // dsd[lo] <= d < dsd[hi]   (B.in_lds: tiles without the tables left above)
+                while (hi - lo > 1) {
+                    const u32 mid = (lo + hi) >> 1;
+                    if ((u32)dsd[mid] <= d) lo = mid; else hi = mid;
+                }
+                pos = base + (u32)dseq[lo] + (d - (u32)dsd[lo]);
+                for (u32 e = 0; e < ne; e++) pos += ext_seq[e] < s_first + lo ? ext_cnt[e] : 0;
+            }
 #ifdef SK_NO_CSR_STORES // (diagnostic builds only: the kernel's time without the CSR stores)
             if (pos == 0xffffffffffffULL) A.out_abund[0] = (u32)tmp[d];
 #else
@@ -1312,7 +1351,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
         const u32 s = L.long_ids[li];
         const u64 b = A.offs[s], e = A.offs[s + 1];
         if (e - b > L.max_len) { // the caller's max_seq_len hint was too small: the host reports it (real maximum != hint)
-            if (tid == 0) A.counts[s] = 0;
+            if (tid == 0) { A.counts[s] = 0; A.kept[s] = 0; }
             continue;
         }
         const u32 len = (u32)(e - b);
@@ -1402,7 +1441,10 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
                 L.lg_abund[b + flag[p]] = abd[p];
             }
         }
-        if (tid == 0) A.counts[s] = n_distinct;
+        if (tid == 0) {
+            A.counts[s] = n_distinct; A.kept[s] = n_kept;
+            if (n_kept != n_distinct) atomicAdd((unsigned long long *)A.drops_out, (unsigned long long)(n_kept - n_distinct));
+        }
         SK_LONG_SYNC();
     }
 }
@@ -1411,7 +1453,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_long(sk_long_args L) {
 // CSR assembly: only medium / long sequences need a copy (their runs were produced in side buffers
 // before the tile kernel fixed their CSR positions); one workgroup per such sequence.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u32 *n_ids_dev, u32 ids_cap, const u64 *offs, const u64 *csr, const u64 *lg_hash,
+__global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u32 *n_ids_dev, u32 ids_cap, const u64 *offs, const u64 *csr, const u32 *counts, const u64 *lg_hash,
                                                     const u32 *lg_abund, u64 *hashes, u32 *abunds, u64 out_cap, u64 *part_keys,
                                                     u32 *part_vals, u32 *part_cursor, u64 part_cap, u32 part_K,
                                                     u32 part_mask, u32 part_sub_shift, u32 *status, u32 part_s) {
@@ -1422,7 +1464,7 @@ __global__ __launch_bounds__(256) void k_place_long(const u32 *ids, const u32 *n
     for (u32 li = blockIdx.x; li < n_ids; li += gridDim.x) {
     const u32 s = ids[li];
     const u64 dst = csr[s], src = offs[s];
-    u64 n = csr[s + 1] - dst;
+    u64 n = counts[s]; // (distinct hashes: the head of the sequence's slot)
     if (n > offs[s + 1] - src) n = offs[s + 1] - src; // (a run is never longer than its sequence)
     for (u64 i = threadIdx.x; i < n; i += 256) {
         const u64 h = lg_hash[src + i];
@@ -1759,7 +1801,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
 
     int st = KS_OK;
     u64 *d_stats = nullptr;
-    u32 *counts = nullptr;
+    u32 *kept = nullptr;
     u32 *med_ids = nullptr, *long_ids = nullptr, *n_cls = nullptr, *tile_first = nullptr, *ticket = nullptr, *part_snap = nullptr;
     unsigned long long *tile_status = nullptr, *tile_status_free = nullptr;
     u64 *slab64 = nullptr, *lg_hash = nullptr;
@@ -1802,6 +1844,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
 #define SK_HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { st = ks_fail(ctx, KS_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); goto done; } } while (0)
 
     SK_CHECK(ks_alloc(ctx, &S->d_offsets, (size_t)n_seqs + 1));
+    SK_CHECK(ks_alloc(ctx, &S->d_counts, (size_t)n_seqs + 1));
     if (n_seqs == 0) {
         SK_HIPCHECK(hipMemsetAsync(S->d_offsets, 0, sizeof(u64), ctx->stream));
         SK_CHECK(ks_alloc(ctx, &S->d_hashes, 1));
@@ -1906,7 +1949,6 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             if (!(variant & 2) && strtoull(f, nullptr, 10) < out_cap) out_cap = strtoull(f, nullptr, 10);
         SK_CHECK(ks_alloc(ctx, &S->d_hashes, (size_t)out_cap));
         SK_CHECK(ks_alloc(ctx, &S->d_abunds, (size_t)out_cap));
-        SK_CHECK(ks_alloc(ctx, &counts, (size_t)n_seqs));
 
         sk_args A;
         memset(&A, 0, sizeof A);
@@ -1919,7 +1961,8 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         A.lut = ctx->d_lut + 256 * p->moltype;
         A.upper_only = p->moltype == KS_PROTEIN ? 1u : 0u;
         if (const char *f = ks_dbg(ctx, KS_DBG_QCAP)) A.debug_qcap = (u32)atoi(f);
-        A.counts = counts;
+        A.counts = S->d_counts;
+        A.drops_out = d_stats + 24;
         A.span = SK_TILE; A.c_div = 1; A.c_rcp = 0; A.out_cap = out_cap; A.max_len_tile = 0xffffffffu; A.R = 1;
         A.ticket = ticket; A.total_out = d_stats + 23;
         if (part_pbits > 0 && S->n_windows > 0 && S->n_windows < 0xffff0000ULL) {
@@ -1958,6 +2001,8 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
 
         // ---- medium / long sequences first: their unique counts feed the tile kernel's CSR prefix
         if (n_med + n_long > 0) {
+            SK_CHECK(ks_alloc(ctx, &kept, (size_t)n_seqs));
+            A.kept = kept;
             SK_CHECK(ks_alloc(ctx, &lg_hash, (size_t)n_res + 1));
             SK_CHECK(ks_alloc(ctx, &lg_abund, (size_t)n_res + 1));
             SK_CHECK(ks_alloc(ctx, &med_ids, (size_t)n_med + 1));
@@ -2070,7 +2115,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                 // medium runs: copy only (their tiles emitted their own postings)
                 hipLaunchKernelGGL(k_place_long, dim3((u32)(n_med < 1024 ? n_med : 1024)), dim3(256), 0, ctx->stream, (const u32 *)med_ids,
                                    (const u32 *)n_cls, (u32)n_med, d_offs,
-                                   (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds, out_cap,
+                                   (const u64 *)S->d_offsets, (const u32 *)S->d_counts, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds, out_cap,
                                    (u64 *)nullptr, (u32 *)nullptr, (u32 *)nullptr, (u64)0, 0u, 0u, 0u, ticket, 0u);
                 ks_timer_end(ctx);
             }
@@ -2078,7 +2123,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                 ks_timer_begin(ctx, "place_long");
                 hipLaunchKernelGGL(k_place_long, dim3((u32)(n_long < 1024 ? n_long : 1024)), dim3(256), 0, ctx->stream, (const u32 *)long_ids,
                                    (const u32 *)(n_cls + 1), (u32)n_long, d_offs,
-                                   (const u64 *)S->d_offsets, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds, out_cap,
+                                   (const u64 *)S->d_offsets, (const u32 *)S->d_counts, (const u64 *)lg_hash, (const u32 *)lg_abund, S->d_hashes, S->d_abunds, out_cap,
                                    A.part_keys, A.part_vals, A.part_cursor, A.part_cap, A.part_K, A.part_mask, A.part_sub_shift, ticket, A.part_s);
                 ks_timer_end(ctx);
             }
@@ -2089,7 +2134,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
                 // (ks_sketch_pending_seg); everything else of this call that is freed below is reused in stream order
                 S->pend_stats = d_stats;
                 S->pending = 1; S->pend_out_cap = out_cap; S->pend_max_seq_len = max_seq_len; S->pend_planned = planned ? 1 : 0;
-                S->n_hashes = out_cap; // (an upper bound until ks_sketch_finish_pending)
+                S->n_hashes = S->n_slots = out_cap; // (upper bounds until ks_sketch_finish_pending)
                 break;
             }
             {
@@ -2101,7 +2146,10 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             if (!(status_w & 1u) || A.use_ticket) break;
         }
         if (S->pending) goto done;
-        S->n_hashes = ctx->h_pin[23];
+        // the CSR's slots hold the kept hashes; the distinct ones (the sketches) are fewer by the repeats
+        S->n_slots = ctx->h_pin[23];
+        S->n_hashes = S->n_slots - (ctx->h_pin[24] < S->n_slots ? ctx->h_pin[24] : S->n_slots);
+        S->gapped = S->n_hashes != S->n_slots;
         if (planned) {
             S->n_windows = ctx->h_pin[0];
             if (ctx->h_pin[1] > (u64)max_seq_len) { // the plan was made for shorter sequences: nothing of this launch can be trusted
@@ -2114,7 +2162,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
             const u32 status = ((u32 *)(ctx->h_pin + 20))[1];
             if (status & 1u) { st = ks_fail(ctx, KS_ERR_HIP, "sketch: tile look-back timed out"); goto done; }
             if (status & 4u) { *redo = 1; goto done; }          // a compacting tile overflowed: the plain variant always fits
-            if (S->n_hashes > out_cap) { *redo = 2; goto done; } // more kept hashes than the bounded outputs hold
+            if (S->n_slots > out_cap) { *redo = 2; goto done; } // more kept hashes than the bounded outputs hold
             if (status & 2u) { // a region overflowed (skewed hashes) or a tile could not code its sequences: no postings,
                                // ks_search repartitions from the CSR instead
                 ks_pool_free(ctx, S->part_keys); ks_pool_free(ctx, S->part_vals); // (part_len lies in the control block)
@@ -2124,7 +2172,7 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
     }
 
 done:
-    ks_pool_free(ctx, counts); ks_pool_free(ctx, tile_first); ks_pool_free(ctx, tile_status_free); ks_pool_free(ctx, part_snap);
+    ks_pool_free(ctx, kept); ks_pool_free(ctx, tile_first); ks_pool_free(ctx, tile_status_free); ks_pool_free(ctx, part_snap);
     ks_pool_free(ctx, med_ids); ks_pool_free(ctx, long_ids);
     ks_pool_free(ctx, slab64); ks_pool_free(ctx, slab32); ks_pool_free(ctx, lg_hash); ks_pool_free(ctx, lg_abund);
     ks_pool_free(ctx, pk_tiles); ks_pool_free(ctx, pk_cnt); ks_pool_free(ctx, tile_g0);
@@ -2150,7 +2198,9 @@ int ks_sketch_finish_pending(ks_sketches *S, int *redo) {
     const u64 *stats = ctx->h_pin + KS_PIN_SKETCH;
     S->pending = 0;
     S->pend_stats = nullptr; // (lies in the control block, which the object keeps)
-    S->n_hashes = stats[23];
+    S->n_slots = stats[23];
+    S->n_hashes = S->n_slots - (stats[24] < S->n_slots ? stats[24] : S->n_slots);
+    S->gapped = S->n_hashes != S->n_slots;
     if (S->pend_planned) {
         S->n_windows = stats[0];
         if (stats[1] > (u64)S->pend_max_seq_len)
@@ -2160,7 +2210,7 @@ int ks_sketch_finish_pending(ks_sketches *S, int *redo) {
     const u32 status = ((const u32 *)(stats + 20))[1];
     if (status & 1u) *redo = 3;                       // a look-back gave up: the plain call repeats the launch with tickets
     else if (status & 4u) *redo = 1;                  // a compacting tile overflowed
-    else if (S->n_hashes > S->pend_out_cap) *redo = 2; // more kept hashes than the bounded outputs hold
+    else if (S->n_slots > S->pend_out_cap) *redo = 2;  // more kept hashes than the bounded outputs hold
     else if (status & 2u) *redo = 4;                  // postings dropped (skewed hashes): whoever read them read garbage
     return KS_OK;
 }
