@@ -860,7 +860,6 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     const u32 n_distinct = n_kept - n_rep;
     const bool posts = A.part_keys != nullptr && B.in_lds; // (uniform)
     if (tid == 0 && n_rep) atomicAdd((unsigned long long *)A.drops_out, (unsigned long long)n_rep); // slots the CSR leaves empty
-
     SK_STAMP_AT(5);
     // ---- phase 6 (tiles with repeats, tiles that emit postings): every thread takes 8 consecutive SORTED positions back into
     // registers (the LDS buffers are reused below).  A hash that equals its left neighbour inside the same sequence is a
@@ -873,7 +872,6 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     u32 ab[SK_E / 2];     // abundance of my representatives, 16 bits each (<= SK_TILE)
 #pragma unroll
     for (int i = 0; i < SK_E / 2; i++) ab[i] = 0x00010001u;
-    u64 hs[SK_E]; // (fast posting path) my 8 sorted positions, to stage the CSR run again behind the postings
     const bool fastp = early && !any_dup; // (uniform)
     if (early && any_dup) { // the ranks taken while hashing counted the repeats too: count again below
         if (tid < 256) bins[tid] = 0;
@@ -886,14 +884,6 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             rep |= (kept ? 1u : 0u) << i;
             srl[i >> 2] |= (kept ? (bo[i] >> 24) : 0u) << (8 * (i & 3));
             rk[i] = (rkp[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-        }
-        if (MODE == 0 && p0 < n_kept) { // (a medium tile writes its run out of tmp before its postings go through it)
-            const uint4 a = *(const uint4 *)&tmp[p0], b = *(const uint4 *)&tmp[p0 + 2], c = *(const uint4 *)&tmp[p0 + 4],
-                        d = *(const uint4 *)&tmp[p0 + 6];
-            hs[0] = (u64)a.x | ((u64)a.y << 32); hs[1] = (u64)a.z | ((u64)a.w << 32);
-            hs[2] = (u64)b.x | ((u64)b.y << 32); hs[3] = (u64)b.z | ((u64)b.w << 32);
-            hs[4] = (u64)c.x | ((u64)c.y << 32); hs[5] = (u64)c.z | ((u64)c.w << 32);
-            hs[6] = (u64)d.x | ((u64)d.y << 32); hs[7] = (u64)d.z | ((u64)d.w << 32);
         }
     } else
     if (any_dup || posts) { // (uniform)
@@ -1038,13 +1028,18 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                 abund_s[d] = (u16)(ab[i >> 1] >> ((i & 1) * 16));
             }
     };
-    // Postings, step 2: a slice of every digit's region for this tile (one device atomic per digit, requested here and
-    // awaited only when the slices are stored), digit starts inside the tile.
-    auto post_offsets = [&]() {
-        const u32 c = tid < 256 ? bins[tid] : 0;
-        u32 off = 0;
-        const u32 seg = (tid << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u)); // (blockIdx.x & 7 names the XCD, i.e. the L2, these writes go through)
-        if (c) off = atomicAdd(&A.part_cursor[seg], c);
+    // Postings, step 2: a slice of every digit's region for this tile — one device atomic per digit, REQUESTED by post_reserve
+    // as soon as the digit counts stand and awaited by post_slices only when the slices are about to be stored (a shared tile
+    // does its look-back and writes its CSR run in between: the atomics' round trip hides behind the look-back's) —, and the
+    // digit starts inside the tile.
+    u32 p_cnt = 0, p_off = 0;
+    const u32 p_seg = (tid << A.part_sub_shift) | (blockIdx.x & ((1u << A.part_sub_shift) - 1u)); // (blockIdx.x & 7 names the XCD, i.e. the L2, these writes go through)
+    auto post_reserve = [&]() {
+        p_cnt = tid < 256 ? bins[tid] : 0;
+        if (p_cnt) p_off = atomicAdd(&A.part_cursor[p_seg], p_cnt);
+    };
+    auto post_slices = [&]() {
+        const u32 c = p_cnt, off = p_off, seg = p_seg;
         const u32 ex = sk_block_excl_scan1(c, scan_smem);
         if (tid < 256) {
             // element i of the digit-ordered tile goes to slot gaddr[digit] + i (the digit's start inside the tile taken off,
@@ -1103,36 +1098,21 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             A.out_abund[r0 + d] = any_dup ? (u32)abund_s[d] : 1u;
         }
         if (posts) { // a medium tile emits its own postings
-            post_offsets();
+            post_reserve();
+            post_slices();
             __syncthreads();
             post_emit();
         }
     } else {
-        // The look-back below waits for the predecessors' aggregates, and a predecessor publishes only after its own sort /
-        // unique phases.  What does not need the tile's CSR base goes HERE, between publication and look-back: the posting
-        // slices, the distinct rank of every sequence start, the staging of a tile with repeats.
-        if (posts) post_offsets();
+        // The CSR run leaves first, the postings behind it.  (Round 3 had it the other way round — the postings filled the
+        // wait for the predecessors' aggregates, at the price of reading the sorted run back into registers and staging it
+        // again behind the postings' digit order; now that the aggregates are published before the sort, the look-back is one
+        // round trip, and the postings' own round trip — the slice reservations — is what hides behind it.)
+        if (posts) post_reserve();
         if (B.in_lds && any_dup) // distinct rank at every sequence start (dseq keeps the kept ranks: they place the slots)
             for (u32 i = tid; i <= ns; i += SK_THREADS) dsd[i] = (u16)drank(dseq[i]);
         if (tid < ne) ext_d[tid] = B.in_lds ? (u32)dseq[ext_seq[tid] - s_first] : bstart(B.at(ext_seq[tid])); // kept rank at which the deferred sequence's slot opens
-        if (posts) { // the postings leave first: their digit order goes through tmp, the sorted run is staged again behind them
-            __syncthreads();
-            post_emit();
-            __syncthreads();
-            if (fastp) {
-#pragma unroll
-                for (int i = 0; i < SK_E; i++) h[i] = hs[i];
-            }
-        }
-        if (B.in_lds) { // bucket starts are dead (dseq holds what the CSR needs)
-            if (any_dup) stage_reps();
-            else if (posts && p0 < n_kept) { // the sorted run as it was: 8 consecutive positions per thread
-                *(uint4 *)&tmp[p0] = make_uint4((u32)h[0], (u32)(h[0] >> 32), (u32)h[1], (u32)(h[1] >> 32));
-                *(uint4 *)&tmp[p0 + 2] = make_uint4((u32)h[2], (u32)(h[2] >> 32), (u32)h[3], (u32)(h[3] >> 32));
-                *(uint4 *)&tmp[p0 + 4] = make_uint4((u32)h[4], (u32)(h[4] >> 32), (u32)h[5], (u32)(h[5] >> 32));
-                *(uint4 *)&tmp[p0 + 6] = make_uint4((u32)h[6], (u32)(h[6] >> 32), (u32)h[7], (u32)(h[7] >> 32));
-            }
-        }
+        if (B.in_lds && any_dup) stage_reps(); // (bucket starts are dead: dseq holds what the CSR needs; phase 6 has read the sorted run)
         SK_STAMP_AT(6);
         // ---- step 2: the predecessors' aggregates are summed back to the nearest inclusive prefix, SK_THREADS predecessors at a
         // time: wave w looks at the 64 tiles behind tile - 64 w.  (One wave looking back 64 at a time cost 0.5 ms of a 2.5 ms
@@ -1172,6 +1152,9 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
 #pragma unroll
                 for (u32 w = 0; w < SK_LB_WAVES; w++)
                     if (!found) { excl += lb_sum[w]; found = lb_pre[w] != 0; }
+#ifdef SK_LB_STATS // (diagnostic builds only: look-back rounds per launch, printed by the host)
+                if (tid == 0) atomicAdd((unsigned long long *)(A.drops_out + 1), 1ULL);
+#endif
                 if (found) break;
                 idx -= 64 * SK_LB_WAVES;
                 __syncthreads(); // (lb_sum / lb_pre are written again)
@@ -1245,6 +1228,12 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             }
 #endif
         }
+    }
+    if (MODE == 0 && posts) { // the postings: digit order through tmp and the counter words, which the CSR run has just left
+        __syncthreads();
+        post_slices();
+        __syncthreads();
+        post_emit();
     }
     if (A.part_keys && !B.in_lds) { // sequence ids do not fit the element code: let the host repartition this batch
         if (tid == 0) atomicOr(&A.ticket[1], 2u);
@@ -2148,6 +2137,9 @@ static int sketch_attempt(ks_ctx *ctx, const u8 *d_res, const u64 *d_offs, u32 n
         if (S->pending) goto done;
         // the CSR's slots hold the kept hashes; the distinct ones (the sketches) are fewer by the repeats
         S->n_slots = ctx->h_pin[23];
+#ifdef SK_LB_STATS
+        fprintf(stderr, "[SK_LB_STATS] tiles %llu look-back rounds %llu\n", (unsigned long long)n_tiles, (unsigned long long)ctx->h_pin[25]);
+#endif
         S->n_hashes = S->n_slots - (ctx->h_pin[24] < S->n_slots ? ctx->h_pin[24] : S->n_slots);
         S->gapped = S->n_hashes != S->n_slots;
         if (planned) {
