@@ -173,22 +173,35 @@ KS_DEV bool sk_deferred(u64 start, u64 len, u32 R, u32 span) { return start % R 
 KS_DEV u32 sk_div(u32 x, u32 d, u32 rcp) { return d == 1 ? x : __umulhi(x, rcp); }
 
 // Block-wide exclusive scan of two values at once (SK_THREADS threads; `smem` holds 2 * (SK_THREADS / 64 + 1) words).
+// The wave totals are combined without a second barrier and without every thread adding them up itself (round 3: 8 x 2 LDS
+// reads + a compare / select / add each per thread — a quarter of phase 3's vector instructions): lane j < 8 of every wave
+// reads total j, three DPP steps scan the eight, and the wave's own base / the tile total are READ from lanes wave - 1 / 7
+// (the wave number is uniform: v_readlane).
+KS_DEV u32 sk_wave_totals_scan(const u32 *smem, u32 lane, u32 wave_u /* uniform */, u32 *total) {
+    constexpr u32 NW = SK_THREADS / 64;
+    static_assert(NW <= 16, "one DPP row");
+    u32 v = lane < NW ? smem[lane] : 0u;
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); // row_shr:4
+    if (NW > 8) v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); // row_shr:8
+    *total = (u32)__builtin_amdgcn_readlane((int)v, NW - 1);
+    return wave_u ? (u32)__builtin_amdgcn_readlane((int)v, (int)wave_u - 1) : 0u;
+}
 KS_DEV u32 sk_block_excl_scan2(u32 a, u32 b, u32 *smem, u32 *total_a, u32 *excl_b) {
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr u32 NW = SK_THREADS / 64;
     const u32 ia = ks_wave_incl_scan(a), ib = ks_wave_incl_scan(b);
     if (lane == 63) { smem[wave] = ia; smem[NW + 1 + wave] = ib; }
     __syncthreads();
-    u32 base_a = 0, base_b = 0, tot_a = 0, tot_b = 0;
-#pragma unroll
-    for (u32 wv = 0; wv < NW; wv++) { // (8 wave totals: every thread sums them itself — no second barrier)
-        const u32 va = smem[wv], vb = smem[NW + 1 + wv];
-        base_a += wv < wave ? va : 0u; base_b += wv < wave ? vb : 0u;
-        tot_a += va; tot_b += vb;
-    }
-    *total_a = tot_a;
+    const u32 wave_u = (u32)__builtin_amdgcn_readfirstlane((int)wave);
+    u32 tot_b;
+    const u32 base_a = sk_wave_totals_scan(smem, lane, wave_u, total_a);
+    const u32 base_b = sk_wave_totals_scan(smem + NW + 1, lane, wave_u, &tot_b);
     *excl_b = base_b + ib - b;
-    if (threadIdx.x == 0) smem[NW] = tot_b; // tile totals of b for whoever reads them after the caller's next barrier
+    // tile totals of b for whoever reads them after the caller's next barrier.  (smem[NW] is read by nobody in this scan, and the
+    // caller's previous use of it lies behind the barrier above.)
+    if (threadIdx.x == 0) smem[NW] = tot_b;
     return base_a + ia - a;
 }
 
@@ -198,9 +211,8 @@ KS_DEV u32 sk_block_excl_scan1(u32 a, u32 *smem) {
     const u32 ia = ks_wave_incl_scan(a);
     if (lane == 63) smem[wave] = ia;
     __syncthreads();
-    u32 base = 0;
-#pragma unroll
-    for (u32 wv = 0; wv < SK_THREADS / 64; wv++) base += wv < wave ? smem[wv] : 0u;
+    u32 total;
+    const u32 base = sk_wave_totals_scan(smem, lane, (u32)__builtin_amdgcn_readfirstlane((int)wave), &total);
     return base + ia - a;
 }
 
@@ -713,7 +725,10 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         for (int j = 0; j < 4; j++) {
             ge2 |= (((w[j] + 0x7ffe7ffeu) & 0x80008000u) >> 15) << j;
             ge3 |= (((w[j] + 0x7ffd7ffdu) & 0x80008000u) >> 15) << j;
-            big |= (((w[j] + (0x8000u - SK_C3MAX - 1u) * 0x00010001u) & 0x80008000u) >> 15) << j;
+        }
+        if (s > SK_C3MAX) { // (a bucket of more than SK_C3MAX hashes needs that many among my eight: rare)
+#pragma unroll
+            for (int j = 0; j < 4; j++) big |= (((w[j] + (0x8000u - SK_C3MAX - 1u) * 0x00010001u) & 0x80008000u) >> 15) << j;
         }
         u32 m2 = ge2 & ~ge3, m3 = ge3 & ~big;
         const u32 code = (u32)__popc(m2) | ((u32)__popc(m3) << 12) | ((u32)__popc(big) << 24); // (tile totals fit the fields)
@@ -1205,6 +1220,9 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         SK_STAMP_AT(7);
         // ---- phase 8: coalesced write-out straight into the final CSR arrays (runs of medium / long neighbours
         // leave gaps that k_place_long fills)
+        // (Measured, round 4: four of a thread's rounds at once — four LDS reads in flight, then eight stores back to back — made
+        // the query launch 4 % SLOWER, and the same unrolling of the posting stores 1.5 %: bursts of stores delay the loads and
+        // atomics other workgroups of the CU are waiting for.  One element per round it stays.)
         for (u32 d = tid; d < ((!B.in_lds && any_dup) ? 0u : n_distinct); d += SK_THREADS) {
             u64 pos = base + d;
             if (!any_dup) { // (uniform) distinct rank == kept rank: the run leaves as it lies
