@@ -253,6 +253,10 @@ uint64_t ks_hits_n_pair_instances(const ks_hits *h); /* Σ_h q(h)·t(h): matched
  * 0 the sketch kernel's regions were the buckets; 1 regions + one histogram-free bucket scatter;
  * 2 regions + one dense radix pass (a bucket overflowed); 3 dense radix partition from the CSR (no postings attached) */
 int ks_hits_partition_path(const ks_hits *h);
+/* Bytes per query posting inside the join buckets of the search that produced h: 12 (hash u64 + sequence id u32), 10 (the
+ * sketch kernel's 10-byte form kept through the bucket scatter), 9 (join prefixes of 16 bits: the bucket implies two hash bytes
+ * and carries two bytes of the sequence id there), 0 (the search ran without the histogram-free bucket scatter).  Diagnostic. */
+int ks_hits_bucket_posting_bytes(const ks_hits *h);
 int ks_hits_copy_to_host(ks_ctx *ctx, const ks_hits *h, uint32_t *qid, uint32_t *tid,
                          uint32_t *intersect, uint64_t *n_weighted);
 /* Device-resident COO columns (valid until ks_hits_free; ks_hits_count entries each) — what a multi-GPU caller hands to

@@ -103,6 +103,7 @@ SIGNATURES = {
     "ks_hits_count": (C.c_uint64, [_vp]),
     "ks_hits_n_pair_instances": (C.c_uint64, [_vp]),
     "ks_hits_partition_path": (C.c_int, [_vp]),
+    "ks_hits_bucket_posting_bytes": (C.c_int, [_vp]),
     "ks_hits_copy_to_host": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "ks_hits_device_qid": (_vp, [_vp]),
     "ks_hits_device_tid": (_vp, [_vp]),

@@ -384,6 +384,10 @@ extern "C" int ks_hits_partition_path(const ks_hits *h) {
     return ks_guard(nullptr, [&]() -> int { return h ? h->partition_path : -1; 
     });
 }
+extern "C" int ks_hits_bucket_posting_bytes(const ks_hits *h) {
+    return ks_guard(nullptr, [&]() -> int { return h ? h->bucket_posting_bytes : -1;
+    });
+}
 extern "C" int ks_hits_copy_to_host(ks_ctx *ctx, const ks_hits *h, uint32_t *qid, uint32_t *tid, uint32_t *intersect,
                                     uint64_t *n_weighted) {
     return ks_guard(ctx, [&]() -> int {

@@ -45,7 +45,7 @@ struct ks_copy_engine; // ks_copy.hip: pinned staging + host copy threads for pa
     X(STAGED_H2D) X(PLAIN_COPIES) X(PAIRS_LSD) X(MSD_LDS_CAP) X(SCAN_3PASS) X(INDEX_LSD) X(JOIN_FP) X(FP_COARSEN)        \
     X(PAIR_LIMIT) X(PBITS_MAX) X(UNPACKED_PAIRS) X(ONE_CURSOR) X(JOIN_SEGS) X(JOIN_SEG_CAP) X(JOIN_SPARSE) X(UNFUSED_ROWS) \
     X(NO_ROWS_HINT) X(ROWS_TICKET) X(FORCE_ROWS_TICKET_RETRY) X(FORCE_TICKET_RETRY) X(NO_PLAN) X(NO_COMPACT) X(SPAN)      \
-    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP) X(SYNC_API) X(POSTINGS12) X(NO_DEFER) X(BUCKET) X(JOIN_SPLIT) X(SUBSHIFT)
+    X(NO_PACK) X(PLAN_SYNC) X(TILE_R) X(OUT_CAP) X(POOL_CAP) X(THROW) X(QCAP) X(LOOKBACK_SKIP) X(SYNC_API) X(POSTINGS12) X(POSTINGS10) X(NO_DEFER) X(BUCKET) X(JOIN_SPLIT) X(SUBSHIFT)
 enum ks_dbg_id {
 #define KS_DBG_ENUM(n) KS_DBG_##n,
     KS_DBG_LIST(KS_DBG_ENUM)
@@ -274,6 +274,7 @@ struct ks_hits {
     u64 n_hits;
     u64 n_pair_instances;
     int partition_path; // how the query postings reached their join buckets (see ks_hits_partition_path)
+    int bucket_posting_bytes; // bytes per query posting inside the join buckets (12, 10 or 9; 0: no bucket scatter ran)
     u32 *d_qid, *d_tid, *d_isect;
     u64 *d_nw;
     // != NULL: d_nw and d_isect point INTO this block (with the row pass's status words: one allocation, one memset)
@@ -322,7 +323,7 @@ int ks_radix_sort_keys(ks_ctx *ctx, int tag, const u64 *keys_in, u64 *ka, u64 *k
 // UTCL1 translation misses per launch with the digit-major order, 0.02 M with this one — same run time, though)
 #define KS_BSLOT(d, r, n_hi) ((r) * (n_hi) + (d))
 int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, const ks_rs_segments *seg, int shift,
-                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status, u32 n_hi, int vals16);
+                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status, u32 n_hi, int vfmt);
 // index build in three passes (two partition passes + in-LDS bucket sort); *overflowed = 1: use the LSD sort instead
 int ks_index_sort_partitioned(ks_ctx *ctx, const u64 *keys_in, const u64 *vals_in, u64 n, u64 max_hash, u64 *okeys, u32 *otids,
                               u32 *oabunds, u32 *d_max_abund, int *overflowed);

@@ -431,7 +431,9 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
 // irrelevant to the join, so the rank of a record inside its (tile, digit) group is just the return value of one LDS
 // atomic — no ballot matching, no per-wave counters.  A bucket that would overflow raises status[1] and the host
 // redoes the pass the dense (stable, histogrammed) way.
-// V16: the value column is 16 bits wide, in and out (10-byte query postings: ks_sketches::part_s)
+// V16 = 1: the value column is 16 bits wide, in and out (10-byte query postings: ks_sketches::part_s).
+// V16 = 2: 16 bits in, 8 bits out (9-byte postings; join prefixes of 16 bits only): the bucket implies the key's top byte too —
+// it is this pass's digit —, so the low byte of the value moves there and its high byte is the 8-bit column that leaves.
 template <int V16>
 __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout,
                                                                         int shift, const u32 *seg_len, u64 seg_cap,
@@ -494,10 +496,21 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_IPT; r++)
-        if (rank[r] != 0xffffffffu) {
-            rank[r] = dstart[rank[r] >> 16] + (rank[r] & 0xffffu);
-            stage[rank[r]] = key[r];
-        }
+        if (rank[r] != 0xffffffffu) rank[r] = dstart[rank[r] >> 16] + (rank[r] & 0xffffu);
+    u32 vo[V16 == 2 ? RS_IPT : 1]; // V16 = 2: the values in output order, before the keys go through the same buffer
+    if (V16 == 2) {
+        u32 *vstage0 = (u32 *)stage;
+#pragma unroll
+        for (int r = 0; r < RS_IPT; r++)
+            if (rank[r] != 0xffffffffu) vstage0[rank[r]] = val[r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RS_IPT; i++) vo[V16 == 2 ? i : 0] = vstage0[(u32)i * RS_THREADS + tid];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < RS_IPT; r++)
+        if (rank[r] != 0xffffffffu) stage[rank[r]] = key[r];
     __syncthreads();
     u64 gdst[RS_IPT]; // global destination of local slot i*RS_THREADS + tid
 #pragma unroll
@@ -510,10 +523,17 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
             const u32 slot = gbase[d] + (p - dstart[d]);
             if (slot < bcap) {
                 gdst[i] = (u64)KS_BSLOT(d, region, n_hi) * bcap + slot;
-                kout[gdst[i]] = k;
+                if (V16 == 2) {
+                    const u32 v = vo[V16 == 2 ? i : 0];
+                    kout[gdst[i]] = (k & ~(0xffULL << 56)) | ((u64)(v & 0xffu) << 56);
+                    ((u8 *)vout)[gdst[i]] = (u8)(v >> 8);
+                } else {
+                    kout[gdst[i]] = k;
+                }
             }
         }
     }
+    if (V16 == 2) return;
     __syncthreads();
     u32 *vstage = (u32 *)stage;
 #pragma unroll
@@ -860,16 +880,16 @@ int ks_radix_sort_u64(ks_ctx *ctx, int tag, const u64 *keys_in, const u64 *vals_
 
 // One pass, no histogram: segmented postings (regions by the low digit) -> 2^pbits fixed-capacity buckets.
 int ks_bucket_scatter_u32(ks_ctx *ctx, const u64 *keys_in, const u32 *vals_in, const ks_rs_segments *seg, int shift,
-                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status, u32 n_hi, int vals16) {
+                          u32 pfxK, u64 *bkeys, u32 *bvals, u32 *bcur, u32 bcap, unsigned long long *status, u32 n_hi, int vfmt) {
     const u32 tiles_per_seg = (u32)((seg->cap + RS_TILE - 1) / RS_TILE);
     const u32 nblocks = seg->regions * tiles_per_seg;
     ks_timer_begin(ctx, "bucket_scatter");
-    if (vals16)
-        hipLaunchKernelGGL((k_bucket_scatter<1>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in, bkeys, bvals, shift,
-                           seg->len, seg->cap, tiles_per_seg, bcur, bcap, status, pfxK, n_hi, seg->sub_shift);
-    else
-    hipLaunchKernelGGL((k_bucket_scatter<0>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in, bkeys, bvals, shift,
-                       seg->len, seg->cap, tiles_per_seg, bcur, bcap, status, pfxK, n_hi, seg->sub_shift);
+#define BKS_LAUNCH(V_) hipLaunchKernelGGL((k_bucket_scatter<V_>), dim3(nblocks), dim3(RS_THREADS), 0, ctx->stream, keys_in, vals_in, bkeys, bvals, \
+                                          shift, seg->len, seg->cap, tiles_per_seg, bcur, bcap, status, pfxK, n_hi, seg->sub_shift)
+    if (vfmt == 2) BKS_LAUNCH(2); // 16-bit values in, key byte + 8-bit values out (9-byte postings)
+    else if (vfmt == 1) BKS_LAUNCH(1);
+    else BKS_LAUNCH(0);
+#undef BKS_LAUNCH
     ks_timer_end(ctx);
     KS_HIP(ctx, hipGetLastError());
     return KS_OK;

@@ -532,11 +532,15 @@ KS_DEV void jn_confirm_slow(const ks_post *post, u32 p0, u32 c, u64 h, u32 *firs
 // the fingerprint is made of, and every index posting of the bucket holds b's byte there: fingerprints are taken from the raw
 // word and a candidate is confirmed on the other 56 bits — the 10-byte form costs no instruction per posting, one AND per
 // candidate and one extra key read per match.
+// 9-byte form (F10 = 2; behind the bucket scatter of a join on 16 prefix bits): in join bucket b ALL 16 prefix bits [48, 64) are
+// b, so the scatter moves the second byte of the sequence id into the high digit's field too and the value column shrinks to
+// 8 bits: 9 instead of 10 bytes out of the scatter and into the join (0.59 GB less per 1M x 1M step).
 template <int F10> struct jn_qfmt {
     u64 keep, fill;
     u32 s;
     KS_DEV jn_qfmt(int fp_shift, u32 bucket)
-        : keep(F10 ? ~(0xffULL << (32 + fp_shift)) : ~0ULL), fill(F10 ? (u64)(bucket & 0xffu) << (32 + fp_shift) : 0ULL), s(32u + (u32)fp_shift) {}
+        : keep(F10 == 2 ? ~(0xffffULL << 48) : (F10 ? ~(0xffULL << (32 + fp_shift)) : ~0ULL)),
+          fill(F10 == 2 ? (u64)(bucket & 0xffffu) << 48 : (F10 ? (u64)(bucket & 0xffu) << (32 + fp_shift) : 0ULL)), s(32u + (u32)fp_shift) {}
     KS_DEV u64 hash(u64 raw) const { return F10 ? ((raw & keep) | fill) : raw; }
     // fingerprint of a raw key word inside the bucket whose first key is `base`
     KS_DEV u32 fp(u64 raw, u64 base, int shift) const { return F10 ? (u32)((raw - base) >> shift) : jn_fingerprint(raw, base, shift); }
@@ -544,7 +548,12 @@ template <int F10> struct jn_qfmt {
     KS_DEV bool in_range(u64 raw, u64 base) const { return F10 ? true : raw >= base; }
     KS_DEV bool same(u64 post_key, u64 raw) const { return F10 ? (((post_key ^ raw) & keep) == 0) : post_key == raw; }
     KS_DEV u32 qid(const u64 *qk, const u32 *qv, u32 i) const {
+        if (F10 == 2) return ((u32)(qk[i] >> 48) & 0xffffu) | ((u32)((const u8 *)qv)[i] << 16);
         return F10 ? (((u32)(qk[i] >> s) & 0xffu) | ((u32)((const u16 *)qv)[i] << 8)) : qv[i];
+    }
+    // the value column from posting q0 on (its entries are 4, 2 or 1 bytes wide)
+    KS_DEV const u32 *vals_at(const u32 *qv, u64 q0) const {
+        return F10 == 2 ? (const u32 *)((const u8 *)qv + q0) : (F10 ? (const u32 *)((const u16 *)qv + q0) : qv + q0);
     }
 };
 
@@ -634,7 +643,7 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
         for (u64 q0 = qs; q0 < qe; q0 += (u64)JN_THREADS * JN_E) {
             u32 info[JN_E]; // position | run length << 16
             const u64 *qkr = qkeys + q0;
-            const u32 *qir = F10 ? (const u32 *)((const u16 *)qids + q0) : qids + q0; // (16-bit value column: jn_qfmt)
+            const u32 *qir = QF.vals_at(qids, q0); // (narrow value columns: jn_qfmt)
             const u32 nq = (u32)((qe - q0) < (u64)JN_THREADS * JN_E ? (qe - q0) : (u64)JN_THREADS * JN_E); // query postings of this round
             if (q0 != qs || c0 != ts) { // (uniform; the first round's are on their way since the top)
 #pragma unroll
@@ -861,7 +870,7 @@ __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8
     for (u64 q0 = qs; q0 < qe; q0 += JS_QCAP) { // slices of the bucket's queries (one, normally)
         const u32 nq = (u32)((qe - q0) < (u64)JS_QCAP ? (qe - q0) : (u64)JS_QCAP);
         const u64 *qkr = qkeys + q0;
-        const u32 *qir = F10 ? (const u32 *)((const u16 *)qids + q0) : qids + q0; // (16-bit value column: jn_qfmt)
+        const u32 *qir = QF.vals_at(qids, q0); // (narrow value columns: jn_qfmt)
         // ---- the table: counting sort of the slice by fingerprint slot
         u64 h[JS_QE];
 #pragma unroll
@@ -1296,6 +1305,9 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
         for (int way = (pre && pbits > 8) ? 0 : 1; way < 2; way++) {
             if (way == 1 && f10) pre = false;
             const u32 q_s = (way == 0 && f10) ? q->part_s : 0u;
+            // behind the bucket scatter of a 16-bit join prefix both prefix bytes are implied by the bucket: 9-byte postings
+            // (KS_DEBUG_POSTINGS10 keeps the 10-byte form there)
+            const int q_fmt = q_s ? ((pbits == 16 && q_s == 48u && !ks_dbg(ctx, KS_DBG_POSTINGS10)) ? 2 : 1) : 0;
             u64 *qk = nullptr;
             u32 *qv = nullptr;
             const u64 *q_lo = nullptr, *q_hi = nullptr;
@@ -1307,7 +1319,8 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 SE_CHECK(ks_alloc(ctx, &qv0, (size_t)n_buckets * bcap));
                 ks_rs_segments seg{q->part_len, q->part_cap, q->part_regions << q->part_sub_shift, q->part_sub_shift};
                 SE_CHECK(ks_bucket_scatter_u32(ctx, q->part_keys, q->part_vals, &seg, 8, pfxK, qk0, qv0, bcur, bcap, cursor, n_buckets >> 8,
-                                               q->part_s ? 1 : 0)); // (10-byte postings stay 10 bytes: the join decodes them)
+                                               q_fmt)); // (10-byte postings stay 10 bytes, or lose one more: the join decodes them)
+                H->bucket_posting_bytes = q_fmt == 2 ? 9 : (q_fmt == 1 ? 10 : 12);
                 ks_timer_begin(ctx, "bucket_dir");
                 hipLaunchKernelGGL(k_region_dir, dim3((n_buckets + 255) / 256), dim3(256), 0, ctx->stream, (const u32 *)bcur, (u64)bcap,
                                    n_buckets, dir_q, dir_q + n_buckets, n_buckets >> 8);
@@ -1372,11 +1385,11 @@ static int search_core(ks_ctx *ctx, const ks_index *ix, const ks_sketches *q, ks
                 const bool sparse = ix->fp_layout && (ks_dbg(ctx, KS_DBG_JOIN_SPARSE) ? atoi(ks_dbg(ctx, KS_DBG_JOIN_SPARSE)) != 0
                                                                                      : n_q / n_buckets <= (u64)JS_QCAP * 3 / 4);
                 if (sparse)
-                    hipLaunchKernelGGL(q_s ? k_join_sparse<1> : k_join_sparse<0>, dim3(n_buckets), dim3(JS_THREADS), 0, ctx->stream, (const u64 *)qk,
+                    hipLaunchKernelGGL(q_fmt == 2 ? k_join_sparse<2> : (q_fmt ? k_join_sparse<1> : k_join_sparse<0>), dim3(n_buckets), dim3(JS_THREADS), 0, ctx->stream, (const u64 *)qk,
                                        (const u32 *)qv, (const u32 *)ix->d_fp, (const ks_post *)ix->d_post, (const ks_bmeta *)ix->d_bmeta, q_lo,
                                        q_hi, dir_t, pk0, pv0, seg_cap, cursor, n_segs - 1, tbits, abits, ix->fp_shift);
                 else if (ix->fp_layout)
-                    hipLaunchKernelGGL(q_s ? k_join_buckets<1> : k_join_buckets<0>, dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
+                    hipLaunchKernelGGL(q_fmt == 2 ? k_join_buckets<2> : (q_fmt ? k_join_buckets<1> : k_join_buckets<0>), dim3(n_buckets), dim3(JN_THREADS), 0, ctx->stream, (const u64 *)qk,
                                        (const u32 *)qv, (const u32 *)ix->d_fp, (const ks_post *)ix->d_post, (const ks_bmeta *)ix->d_bmeta, q_lo,
                                        q_hi, dir_t, pk0, pv0, seg_cap, cursor, n_segs - 1, tbits, abits, ix->fp_shift);
                 else {

@@ -500,6 +500,11 @@ class Hits(_Owned):
         """0 sketch regions == buckets, 1 regions + bucket scatter, 2 regions + dense pass, 3 dense from the CSR."""
         return int(self._ctx._L.ks_hits_partition_path(self._h))
 
+    @property
+    def bucket_posting_bytes(self) -> int:
+        """Bytes per query posting inside the join buckets (12 / 10 / 9; 0 = no bucket scatter ran)."""
+        return int(self._ctx._L.ks_hits_bucket_posting_bytes(self._h))
+
     def device_ptrs(self) -> Tuple[int, int, int, int]:
         """Raw device pointers of the COO columns (qid u32, tid u32, intersect u32, n_weighted u64), `count` entries each."""
         L = self._ctx._L

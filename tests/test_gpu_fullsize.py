@@ -100,6 +100,7 @@ def test_baseline_configs3_1M_vs_1M_protein_k10_full_size(ctx):
         assert Q.has_postings
         H = ctx.search(index, Q)
         assert H.partition_path == 1, "the fused postings + histogram-free bucket scatter is the path bench.py times"
+        assert H.bucket_posting_bytes == 9  # (16 join-prefix bits: both prefix bytes are implied behind the scatter)
         qid, tid, isect, nw = H.to_host()
         n_pairs = H.n_pair_instances
         # ---- sketches vs the oracle on >= 2k sequences spread over each batch (first / last tiles included)

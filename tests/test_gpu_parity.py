@@ -413,6 +413,51 @@ def test_presorted_query_postings_equal_plain_search(ctx, k, scaled, mol, nt, nq
 
 
 @pytest.mark.parametrize("sparse", ["0", "1"])
+def test_nine_byte_bucket_postings_equal_plain_search(ctx, monkeypatch, sparse):
+    """Behind the bucket scatter of a join on 16 prefix bits (here forced on a 16k-protein index: KS_DEBUG_BUCKET) the bucket
+    implies BOTH prefix bytes of a hash, so the scatter moves the second byte of the sequence id into the key as well and the
+    value column is 8 bits wide: 9-byte postings into both fingerprint joins.  Same rows as the plain search and as the
+    10-byte form (KS_DEBUG_POSTINGS10); sequence ids beyond 2^16 (all three id bytes in use), repeated proteins included."""
+    monkeypatch.setenv("KS_DEBUG_JOIN_SPARSE", sparse)
+    monkeypatch.setenv("KS_DEBUG_BUCKET", "64")
+    k, scaled, mol = 10, 1, "protein"
+    t_res, t_off = synth.proteome(16000, stream=290)
+    q_res, q_off = synth.queries(5000, t_res, t_off, stream=291)
+    seqs = [bytes(q_res[int(q_off[i]):int(q_off[i + 1])]) for i in range(5000)]
+    short = [s[o:o + 40] for s in seqs for o in range(0, len(s) - 39, 20)]   # ~70,000 short sequences: ids well beyond 2^16
+    seqs = seqs[:100] + seqs[100:] + short + [seqs[7]] * 40
+    assert len(seqs) > 70000
+    q_res, q_off = ks.pack(seqs)
+    T = ctx.sketch_batch(t_res, t_off, k, scaled, mol)
+    ix = ctx.index_build(T)
+    want = ctx.search(ix, ctx.sketch_batch(q_res, q_off, k, scaled, mol)).to_host()
+    assert len(want[0]) > 10000 and int(want[0].max()) > 70000
+    d_res, d_off = ctx.to_device(q_res), ctx.to_device(q_off)
+    Q = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
+    assert Q.posting_bytes == 10
+    H = ctx.search(ix, Q)
+    assert H.partition_path == 1 and H.bucket_posting_bytes == 9
+    for g, w in zip(H.to_host(), want):
+        assert np.array_equal(g, w)
+    Q1, H1 = ctx.sketch_search_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))  # the one-call entry takes the same path
+    assert H1.bucket_posting_bytes == 9
+    for g, w in zip(H1.to_host(), want):
+        assert np.array_equal(g, w)
+    monkeypatch.setenv("KS_DEBUG_POSTINGS10", "1")
+    H10 = ctx.search(ix, Q)
+    assert H10.partition_path == 1 and H10.bucket_posting_bytes == 10
+    for g, w in zip(H10.to_host(), want):
+        assert np.array_equal(g, w)
+    monkeypatch.delenv("KS_DEBUG_POSTINGS10")
+    monkeypatch.setenv("KS_DEBUG_POSTINGS12", "1")
+    Q12 = ctx.sketch_queries_device(ix, d_res.ptr, d_off.ptr, len(q_off) - 1, len(q_res))
+    H12 = ctx.search(ix, Q12)
+    assert H12.bucket_posting_bytes == 12
+    for g, w in zip(H12.to_host(), want):
+        assert np.array_equal(g, w)
+
+
+@pytest.mark.parametrize("sparse", ["0", "1"])
 def test_ten_byte_query_postings_equal_plain_search(ctx, monkeypatch, sparse):
     """Against an index in the fingerprint layout at scaled = 1 (pbits > 8) the sketch kernel emits 10-byte postings (8 hash
     bits are implied by the region: the low byte of the sequence id rides there, the rest in a 16-bit column).  Same
