@@ -485,8 +485,9 @@ def run_queries_sharded(args, env, ks, synth, ksd):
                 floor_s = (q_windows / 64.0) * 123 * 4 / simds / clk
                 r["valu_model"] = {"hash_quad_cycles_per_64_windows": 123, "simds": simds, "clock_hz_assumed": clk,
                                    "hash_only_floor_ms": floor_s * 1e3, "launch_over_hash_floor": avg_s / floor_s,
-                                   "note": "SQ counters: 1,871 vector instructions per wave of which ~216 are half-rate multiplies = 2,087 "
-                                           "quad-cycles per wave x 614 waves per SIMD = ~83 % of the launch time (profiles/r03_sq_counters.md)"}
+                                   "note": "SQ counters: 1,686 vector instructions per wave of which ~200 are half-rate multiplies (profiles/r04_sq_counters.md); "
+                                           "diagnostic builds without stores and look-back run the launch in 1.91 ms (DESIGN.md 3.1): the rest is the "
+                                           "chain of phases and the stores, not vector issue"}
         else:
             r["design_bytes_per_launch"] = b
             r["note"] = "scratch pass of the search: bytes it has to move by design, not SURVEY 8(d) algorithmic bytes"
