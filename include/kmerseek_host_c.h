@@ -44,6 +44,9 @@ int ksh_index_search(ksh_index *ix, const char *const *sequences, const char *co
                      char **json_out, char *err, size_t err_cap);
 int ksh_index_search_fasta(ksh_index *ix, const char *fasta_path, uint64_t batch_size, char **json_out, char *err,
                            size_t err_cap);
+/* md5sum field of a sourmash signature — MD5(ascii(3 * protein_ksize) || ascii decimal of every min in order) — as the search rows'
+ * query_md5 / match_md5 columns hold it; out33 receives 32 hex digits + NUL.  Needs no GPU. */
+int ksh_sourmash_md5(const uint64_t *mins, uint64_t n, uint32_t protein_ksize, char *out33);
 uint64_t ksh_index_signature_count(const ksh_index *ix);
 uint64_t ksh_index_combined_minhash_size(const ksh_index *ix);
 uint32_t ksh_index_ksize(const ksh_index *ix);

@@ -893,6 +893,16 @@ int ksh_index_search(ksh_index *ix, const char *const *sequences, const char *co
     })
 }
 
+// sourmash md5sum of a sketch (what the search rows' query_md5 / match_md5 columns hold); needs no GPU
+int ksh_sourmash_md5(const uint64_t *mins, uint64_t n, uint32_t protein_ksize, char *out33) {
+    if ((!mins && n) || !out33) return 1;
+    try {
+        const std::string h = kmerseek::sourmash_md5(mins, (size_t)n, protein_ksize);
+        memcpy(out33, h.c_str(), 33);
+        return 0;
+    } catch (...) { return 1000; }
+}
+
 int ksh_index_search_fasta(ksh_index *ix, const char *fasta_path, uint64_t batch_size, char **json_out, char *err, size_t err_cap) {
     KSH_GUARD({
         if (!ix || !json_out || !fasta_path) throw IndexError(IndexError::ValidationError, "Validation error: NULL argument");

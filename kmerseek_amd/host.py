@@ -31,6 +31,7 @@ HOST_SIGNATURES = {
     "ksh_index_search": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint32, C.c_int,
                                    C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
     "ksh_index_search_fasta": (C.c_int, [C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "ksh_sourmash_md5": (C.c_int, [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_char_p]),
     "ksh_index_signature_count": (C.c_uint64, [C.c_void_p]),
     "ksh_index_combined_minhash_size": (C.c_uint64, [C.c_void_p]),
     "ksh_index_ksize": (C.c_uint32, [C.c_void_p]),
@@ -114,6 +115,16 @@ def decompress(path) -> tuple:
         return C.string_at(data, n.value), fmt.value.decode()
     finally:
         L.ksh_input_free(data)
+
+
+def sourmash_md5(mins, protein_ksize: int) -> str:
+    """md5sum of a sketch as sourmash writes it (native: the search rows' query_md5 / match_md5 come from the same routine)."""
+    import numpy as np
+    a = np.ascontiguousarray(mins, dtype=np.uint64)
+    out = C.create_string_buffer(33)
+    if _host().ksh_sourmash_md5(a.ctypes.data_as(C.POINTER(C.c_uint64)), len(a), int(protein_ksize), out) != 0:
+        raise IndexError_(1000, "ksh_sourmash_md5 failed")
+    return out.value.decode()
 
 
 def sum_as_string(a: int, b: int) -> str:

@@ -76,3 +76,20 @@ def test_stitching_restatement(search_expected, ced9_records, bcl2_records):
     # the stitcher's quirks are kept: a repeated position re-appends the whole k-mer
     assert wire.single_stitch_together_kmers(["ABC", "BCD", "BCD"], [0, 1, 1]) == "ABCDBCD"
     assert wire.single_stitch_together_kmers(["ABC", "CDE"], [0, 2]) == "ABCDE"
+
+
+def test_native_sourmash_md5_equals_hashlib_and_goldens(golden_sketches):
+    """The md5sum columns of ProteomeIndex.search rows come from an in-file MD5 (ks_host.cpp, RFC 1321): equal to hashlib on
+    every block-boundary length and to the md5sum fields of the reference's golden signatures (tests/testdata/**/*.sig.zip)."""
+    from kmerseek_amd import host
+    rng = np.random.default_rng(9)
+    for n in list(range(0, 12)) + [55, 56, 57, 63, 64, 65, 119, 120, 121, 1000, 4097]:
+        mins = np.sort(rng.integers(1, 2**63, size=n, dtype=np.uint64))
+        for k in (5, 16, 24, 128):
+            assert host.sourmash_md5(mins, k) == wire.sourmash_md5(mins, k)
+    n_checked = 0
+    for key, ksize in (("hp.k15.scaled5", 15), ("hp.k16.scaled5", 16), ("hp.k24.scaled5", 24)):
+        for sig in golden_sketches[key]["signatures"]:
+            assert host.sourmash_md5(np.array(sig["mins"], np.uint64), ksize) == sig["md5sum"]
+            n_checked += 1
+    assert n_checked == 75
