@@ -326,6 +326,7 @@ def run_queries_sharded(args, env, ks, synth, ksd):
     n_t_postings = index.n_postings
 
     posting_bytes = [12]  # bytes per partitioned query posting (10 against a big index at scaled = 1, else 12)
+    bucket_bytes = [12]   # ... and inside the join buckets, behind the bucket scatter (9 when the join prefix has 16 bits)
 
     def step():
         # sketch for an immediate search: the sketch kernel also writes the postings pre-partitioned for the join; one call
@@ -336,6 +337,7 @@ def run_queries_sharded(args, env, ks, synth, ksd):
         else:
             Q, H = ctx.sketch_search_device(index, q_res.data_ptr(), q_off.data_ptr(), n_q, n_q_res, max_seq_len=q_maxlen)
         posting_bytes[0] = Q.posting_bytes or 12
+        bucket_bytes[0] = H.bucket_posting_bytes or posting_bytes[0]
         out = (Q.n_hashes, H.count, H.n_pair_instances)
         H.free()
         Q.free()
@@ -445,16 +447,16 @@ def run_queries_sharded(args, env, ks, synth, ksd):
     # kept hash written + 8 B offset per sequence.  The query launches also write the pre-partitioned postings the search
     # starts from (12 B per kept hash; 10 B against a big index at scaled = 1, where the region implies 8 hash bits): real
     # traffic of this kernel, but a scratch pass of the search — kept apart.
-    pb = posting_bytes[0]
+    pb, bb = posting_bytes[0], bucket_bytes[0]
     sketch_bytes = n_q_res + 12 * n_q_hashes + 8 * n_q
     design_bytes = {
         "sketch_tiles": sketch_bytes,
         # scratch passes of the search (not §8(d) bytes): what each launch has to move by design
-        "bucket_scatter": 2 * pb * n_q_hashes,                            # one posting in, one out
+        "bucket_scatter": (pb + bb) * n_q_hashes,                         # one posting in, one out
         "radix_hist.qpart": 8 * n_q_hashes,
         # query postings read once + the index side once — 4-byte fingerprints for big indexes (>= 2^15 join buckets: the
         # 16-byte posting is fetched per candidate match only), 12-byte postings otherwise — + one 8-B record per match
-        "join_buckets": pb * n_q_hashes + ((4 * n_t_postings + 16 * n_pairs) if (n_t_postings >> 14) > 3072 else 12 * n_t_postings) + 8 * n_pairs,
+        "join_buckets": bb * n_q_hashes + ((4 * n_t_postings + 16 * n_pairs) if (n_t_postings >> 14) > 3072 else 12 * n_t_postings) + 8 * n_pairs,
     }
     traffic_tab, traffic_src = load_traffic(profile_key(args, n_q))
 
@@ -475,6 +477,7 @@ def run_queries_sharded(args, env, ks, synth, ksd):
             r["algorithmic_bytes_formula"] = "n_res + 12*n_hashes + 8*n_seqs (SURVEY 8(d): L + 12*U + 8 per sequence)"
             r["fused_scratch_bytes"] = pb * n_q_hashes  # postings for the join, written by the same launch; not in `achieved`
             r["posting_bytes"] = pb
+            r["bucket_posting_bytes"] = bb
             r["achieved_incl_fused_scratch"] = (b + pb * n_q_hashes) / avg_s / 1e9
             # What this kernel actually runs against (informational; `bound` stays the contract's "hbm"): the vector ALU.  The
             # hash alone is ~75 plain + 24 half-rate (32-bit multiply: aux.device.u64_gmul_per_s_measured) instructions per

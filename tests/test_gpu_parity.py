@@ -412,6 +412,46 @@ def test_presorted_query_postings_equal_plain_search(ctx, k, scaled, mol, nt, nq
             assert np.array_equal(g, w)
 
 
+def test_sketches_with_repeats_are_a_plain_csr_at_the_boundary(ctx):
+    """A sketch call leaves every sequence a slot as long as its KEPT hashes; sequences that repeat a k-mer
+    leave a gap behind their distinct hashes.  None of it shows at the boundary: the device accessors of the ABI, the copies to
+    the host, an index build and a search that starts from the CSR all see the plain CSR (made dense on first sight)."""
+    import torch
+    from kmerseek_amd import dist as ksd
+    rng = np.random.default_rng(3)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    rnd = lambda n: bytes(rng.choice(aa, size=int(n)).tolist())
+    seqs = []
+    for i in range(3000):
+        s_ = rnd(rng.integers(40, 500))
+        seqs.append(s_ + s_[:60] if i % 7 == 0 else s_)      # every seventh sequence repeats its first 60 residues
+    seqs += [b"AC" * 900, rnd(4100) + b"W" * 300]             # ... and a medium / a long sequence with repeats
+    res, offs = ks.pack(seqs)
+    for k, scaled, mol in ((10, 1, "protein"), (16, 5, "hp")):
+        want = oracle.sketch_batch(res, offs, k, scaled, mol, n_threads=8)
+        lens = np.maximum((offs[1:] - offs[:-1]).astype(np.int64) - k + 1, 0)
+        if scaled == 1:
+            assert int(want[0][-1]) < int(lens.sum())          # (the batch really has repeats: fewer distinct hashes than windows)
+        dev = torch.device("cuda", 0)
+        S = ctx.sketch_batch(res, offs, k, scaled, mol)
+        assert S.n_hashes == int(want[0][-1])
+        cols = ksd.sketch_columns_as_torch(S, dev)             # ks_sketches_device_offsets / _hashes / _abunds
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        for g, w in zip(cols, want):
+            assert np.array_equal(g.cpu().numpy().view(w.dtype), w)
+        del cols
+        S2 = ctx.sketch_batch(res, offs, k, scaled, mol)       # index build / CSR search straight from a fresh (gapped) object
+        ix = ctx.index_build(S2)
+        got = ctx.search(ix, ctx.sketch_batch(res, offs, k, scaled, mol)).to_host()
+        diag = got[0] == got[1]
+        sizes = (want[0][1:] - want[0][:-1]).astype(np.int64)
+        assert np.array_equal(got[0][diag], np.flatnonzero(sizes > 0).astype(np.uint32))
+        assert np.array_equal(got[2][diag], sizes[got[0][diag]].astype(np.uint32))   # self hits carry the distinct count
+        for g, w in zip(S2.to_host(), want):
+            assert np.array_equal(g, w)
+
+
 @pytest.mark.parametrize("sparse", ["0", "1"])
 def test_nine_byte_bucket_postings_equal_plain_search(ctx, monkeypatch, sparse):
     """Behind the bucket scatter of a join on 16 prefix bits (here forced on a 16k-protein index: KS_DEBUG_BUCKET) the bucket
