@@ -199,7 +199,11 @@ uint64_t ks_sketches_n_windows(const ks_sketches *s); /* k-mer windows hashed to
  * 2 = 10-byte postings (the fingerprint join of big indexes at scaled = 1: 8 hash bits are implied by the region) */
 int ks_sketches_has_postings(const ks_sketches *s);
 void ks_sketches_params(const ks_sketches *s, ks_params *out);
-/* device pointers (valid until ks_sketches_free): offsets u64[n+1], hashes u64[], abund u32[] */
+/* device pointers (valid until ks_sketches_free): offsets u64[n+1], hashes u64[], abund u32[] — the plain CSR.  (Inside the
+ * library a fresh batch is a CSR of slots: a sequence that repeats a k-mer leaves a gap behind its distinct hashes.  The first
+ * of these calls — like ks_sketches_copy_to_host, ks_index_build, ks_sketches_union — closes the gaps of such a batch with one
+ * gather on the context's stream and waits for it; a batch without repeats is a plain CSR as it stands.  NULL with the reason
+ * in ks_last_error if that pass fails.) */
 const uint64_t *ks_sketches_device_offsets(const ks_sketches *s);
 const uint64_t *ks_sketches_device_hashes(const ks_sketches *s);
 const uint32_t *ks_sketches_device_abunds(const ks_sketches *s);
