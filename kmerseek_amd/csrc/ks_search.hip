@@ -611,7 +611,7 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
         // j = floor(f * JN_DIR / (the bucket's largest + 1)) holds n / JN_DIR of them on average, and a query's search is two
         // directory reads and a search of its slot's few entries instead of log2(n) dependent LDS probes.  ldir[j] = staged
         // fingerprints whose slot is < j: entry j is written by the first fingerprint whose slot is >= j — a thread sees that
-        // from its fingerprint and the one before it (a second, overlapping load).  JN_FILLU of each are in flight before the
+        // from its fingerprint and the one before it (the lane below; a load for lane 0).  JN_FILLU of each are in flight before the
         // LDS stores.
         {
             const u32 s_first = jn_slot(fpc[0], dirM), s_last = jn_slot(fpc[n - 1], dirM); // (uniform; slot 0 unless a later chunk)
@@ -624,8 +624,13 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
             for (int j = 0; j < JN_FILLU; j++) {
                 const u32 i = i0 + (u32)j * JN_THREADS + tid;
                 kk[j] = i < n ? fpc[i] : 0;
-                pp[j] = (i < n && i) ? fpc[i - 1] : 0;
+                pp[j] = 0;
+                if (lane == 0 && i < n && i) pp[j] = fpc[i - 1]; // (one lane per wave: its left neighbour sits in the wave before)
             }
+            // (the fingerprint before mine: consecutive threads hold consecutive fingerprints, so it comes from the lane below —
+            // round 3 loaded it a second time, 9 more global loads per thread: join 1.42 -> 1.40 ms)
+#pragma unroll
+            for (int j = 0; j < JN_FILLU; j++) { const u32 b = ks_lane_below(kk[j]); pp[j] = lane ? b : pp[j]; }
 #pragma unroll
             for (int j = 0; j < JN_FILLU; j++) {
                 const u32 i = i0 + (u32)j * JN_THREADS + tid;
