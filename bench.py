@@ -323,6 +323,14 @@ def run_queries_sharded(args, env, ks, synth, ksd):
     index = ctx.index_build(T)
     torch.cuda.synchronize(env.dev)
     index_build_s = time.time() - t0
+    # ... and once more with the pool warm (the first build pays for every hipMalloc of the context's pool)
+    T.free(); index.free()
+    torch.cuda.synchronize(env.dev)
+    t0 = time.time()
+    T = ctx.sketch_batch_device(t_res.data_ptr(), t_off.data_ptr(), args.targets, n_t_res, k, scaled, mol)
+    index = ctx.index_build(T)
+    torch.cuda.synchronize(env.dev)
+    index_build_warm_s = time.time() - t0
     n_t_postings = index.n_postings
 
     posting_bytes = [12]  # bytes per partitioned query posting (10 against a big index at scaled = 1, else 12)
@@ -543,7 +551,7 @@ def run_queries_sharded(args, env, ks, synth, ksd):
         "query_proteins_per_s": all_queries * args.steps / elapsed,
         "query_windows": all_windows, "query_hashes": all_q_hashes, "index_postings": n_t_postings,
         "hits": all_hits, "matched_posting_pairs": all_pairs,
-        "index_build_s": index_build_s, "datagen_s": gen_s,
+        "index_build_s": index_build_s, "index_build_warm_s": index_build_warm_s, "datagen_s": gen_s,
         "roofline": roofline, "step_roofline": step_roofline, "cpu_baseline": cpu,
         "roofline_other_kernels": roofline_others, "kernels": per_kernel, "aux": aux,
     }
