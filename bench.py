@@ -113,7 +113,20 @@ class Env:
         self.cdev = torch.device("cpu") if self.rehearse else self.dev  # where collective buffers live
         self.backend = None
         self.step_ms, self.tail_ms = [], 0.0
-        if self.world > 1:
+        # KS_BENCH_FORCE_PG=1 with ONE rank: a one-rank "nccl" process group, and every collective of the N-rank path is issued
+        # (kmerseek_amd/dist.py: KS_DIST_FORCE_COLLECTIVES) — the RCCL calls of the N-GPU job executed on a one-GPU box
+        # (tests/test_gpu_rccl.py).  Never the default: the plain N=1 run has no process group and no gather copy.
+        self.force_pg = os.environ.get("KS_BENCH_FORCE_PG") == "1" and self.world == 1 and not self.rehearse
+        self.multi = self.world > 1 or self.force_pg
+        if self.force_pg:
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                port = s_.getsockname()[1]
+            for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", str(port))):
+                os.environ.setdefault(k_, v_)
+            os.environ["KS_DIST_FORCE_COLLECTIVES"] = "1"
+        if self.multi:
             # Fail fast and say why: a rank that does not come up must not leave the others in the backend's default
             # 10-minute wait (the driver's limit for the whole bench is of that order: a hang would look like a slow run).
             from datetime import timedelta
@@ -140,7 +153,7 @@ class Env:
                 os._exit(3)
 
     def barrier(self):
-        if self.world > 1:
+        if self.multi:
             self.dist.barrier()
         self.torch.cuda.synchronize(self.dev)
 
@@ -164,7 +177,7 @@ class Env:
         el = marks[steps + 1] - t0
         self.step_ms = [(marks[i + 1] - marks[i]) * 1e3 for i in range(steps)]
         self.tail_ms = (marks[steps + 1] - marks[steps]) * 1e3  # finalize + closing barrier / synchronize
-        if self.world > 1:
+        if self.multi:
             t = self.torch.tensor([el], dtype=self.torch.float64, device=self.cdev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             el = float(t[0])
@@ -183,12 +196,12 @@ class Env:
 
     def sum_ints(self, vals):
         t = self.torch.tensor(list(vals), dtype=self.torch.int64, device=self.cdev)
-        if self.world > 1:
+        if self.multi:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [int(x) for x in t.tolist()]
 
     def close(self):
-        if self.world > 1:
+        if self.multi:
             self.dist.destroy_process_group()
 
 
@@ -300,7 +313,7 @@ def run_queries_sharded(args, env, ks, synth, ksd):
         q_res, q_off, n_q_res = device_shard(env, qa_res, qa_off, s0, s1)
         n_q = s1 - s0
         q_base = s0
-        if world == 1 or rank != 0:
+        if not env.multi or rank != 0:
             del qa_res, qa_off  # (rank 0 of an N-rank job keeps the whole batch for the sharded == unsharded check)
     else:
         if rank != 0:
@@ -374,7 +387,7 @@ def run_queries_sharded(args, env, ks, synth, ksd):
     timing_all = {k_: (n_ / 2, ms_ / 2) for k_, (n_, ms_) in ctx.timing().items()}
     check = self_check(env, ksd, ctx, index, q_res.data_ptr(), q_off.data_ptr(), n_q, n_q_res, q_maxlen)
     gate = None
-    if world > 1 and strong:
+    if env.multi and strong:
         # every rank's hit list of its query shard, all-gathered (qid ranges ascend with the rank: the concatenation IS the
         # global order) == rank 0 searching all the queries by itself.  (A side check: an error in it — other than a mismatch
         # under KS_BENCH_REHEARSE / KS_BENCH_STRICT — is reported in the line, it does not cost the headline.)
@@ -773,7 +786,7 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
     timing_all = {k_: (n_ / 2, ms_ / 2) for k_, (n_, ms_) in ctx.timing().items()}
     check = self_check(env, ksd, ctx, index, p_res.data_ptr(), p_off.data_ptr(), n_prot, n_res, q_maxlen)
     gate = None
-    if world > 1:
+    if env.multi:
         # the per-shard hit lists gathered and merged into global (qid, tid) order == rank 0's unsharded all-vs-all
         try:
             Q, H = ctx.sketch_search_device(index, p_res.data_ptr(), p_off.data_ptr(), n_prot, n_res, max_seq_len=q_maxlen)
@@ -848,7 +861,7 @@ def run_index_sharded(args, env, ks, synth, ksd, ctx=None, n_prot=None, k=24, sc
         "query_proteins_per_s": n_prot * args.steps / elapsed, "query_windows": q_windows, "query_hashes": stats[0],
         "hits_gathered": n_gathered, "hits_sum_over_shards": local_hits_sum, "gathered_equals_sum_of_shards": n_gathered == local_hits_sum,
         "gathered_pairs_all_distinct": ordered, "self_hits": diag, "matched_posting_pairs_rank0": stats[2],
-        "hit_bytes_gathered_per_step": (8 if world > 1 else 20) * n_gathered, "index_build_s": index_build_s, "datagen_s": gen_s,
+        "hit_bytes_gathered_per_step": (8 if env.multi else 20) * n_gathered, "index_build_s": index_build_s, "datagen_s": gen_s,
     }
 
 

@@ -16,6 +16,7 @@ from the ``ks_hits`` object into the send block, no host staging, no host sort).
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -55,6 +56,17 @@ def world_info() -> Tuple[int, int]:
     return 0, 1
 
 
+def _multi(world: int) -> bool:
+    """Do the collectives run?  With more than one rank, always.  KS_DIST_FORCE_COLLECTIVES=1 makes a ONE-rank process group
+    take the same path (count exchange, packed / unpacked all-gather, broadcasts): on a one-GPU box that is how the RCCL calls
+    themselves — dtypes, device buffers, stream order against the context's launches, async_op / wait — are executed
+    (tests/test_gpu_rccl.py, KS_BENCH_FORCE_PG); results are the same either way."""
+    if world > 1:
+        return True
+    dist = _dist()
+    return os.environ.get("KS_DIST_FORCE_COLLECTIVES") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def broadcast_batch(residues: Optional[np.ndarray], offsets: Optional[np.ndarray], src: int = 0, device=None):
     """Broadcast a (residues u8, offsets u64) batch from `src` to every rank; returns torch tensors on `device`
     (uint8, int64-viewed offsets).  With one rank it just moves the arrays to the device."""
@@ -66,7 +78,8 @@ def broadcast_batch(residues: Optional[np.ndarray], offsets: Optional[np.ndarray
         meta = torch.tensor([len(residues), len(offsets)], dtype=torch.int64, device=dev)
     else:
         meta = torch.zeros(2, dtype=torch.int64, device=dev)
-    if world > 1:
+    multi = _multi(world)
+    if multi:
         dist.broadcast(meta, src)
     if rank == src:
         t_res = torch.from_numpy(np.ascontiguousarray(residues, dtype=np.uint8)).to(dev)
@@ -74,7 +87,7 @@ def broadcast_batch(residues: Optional[np.ndarray], offsets: Optional[np.ndarray
     else:
         t_res = torch.empty(int(meta[0]), dtype=torch.uint8, device=dev)
         t_off = torch.empty(int(meta[1]), dtype=torch.int64, device=dev)
-    if world > 1:
+    if multi:
         dist.broadcast(t_res, src)
         dist.broadcast(t_off, src)
     return t_res, t_off
@@ -110,7 +123,8 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
         hits, on_device = hits.to_host(), False
     n_local = int(hits.count) if on_device else len(hits[0])
     counts = [n_local]
-    if world > 1:
+    multi = _multi(world)
+    if multi:
         mine = torch.tensor([n_local], dtype=torch.int64, device=dev)
         allc = torch.zeros(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allc, mine)
@@ -131,7 +145,7 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
         # when an id does not fit its field, and every rank then takes the unpacked exchange)
         raise ValueError(f"id bases ({qid_base}, {tid_base}) do not fit id_counts {tuple(id_counts)}")
 
-    if (world == 1 and on_device and qid_base == 0 and tid_base == 0
+    if (not multi and on_device and qid_base == 0 and tid_base == 0
             and hits._ctx.stream == torch.cuda.current_stream(dev).cuda_stream):
         # one rank, nothing to shift: the columns of the hit list themselves, as torch views (no 20-byte-per-row D2D copy:
         # 0.9 ms of a 3.9 ms step at 31 M rows); each tensor keeps the ks_hits object alive.  Only when the context launches
@@ -142,7 +156,7 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
         if views is not None:
             return views
 
-    if world > 1 and id_counts is not None:
+    if multi and id_counts is not None:
         qbits, tbits = _bits_for(id_counts[0]), _bits_for(id_counts[1])
         if qbits + tbits <= 48:
             out = _gather_packed(hits, on_device, n_local, counts, qid_base, tid_base, qbits, tbits, dev, own_stream_sync, torch_stream_sync)
@@ -156,7 +170,7 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
 
     # one block per rank, SoA: qid[cap] | tid[cap] | intersect[cap] | n_weighted[cap] (as 2 x i32 each); with one rank
     # the block is exact, so its columns are the result (no second pass)
-    cap = n_local if world == 1 else (max(max(counts), 1) + 63) // 64 * 64
+    cap = n_local if not multi else (max(max(counts), 1) + 63) // 64 * 64
     cap += cap & 1  # even: the i64 column of a block stays 8-byte aligned
     send = torch.empty(max(5 * cap, 2), dtype=torch.int32, device=dev)
     if n_local:
@@ -175,7 +189,7 @@ def all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, device=No
     def columns(blk, c):
         return blk[0:c], blk[cap:cap + c], blk[2 * cap:2 * cap + c], blk[3 * cap:5 * cap].view(torch.int64)[:c]
 
-    if world == 1:
+    if not multi:
         return columns(send, n_local)
     recv = torch.empty(world * 5 * cap, dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(recv, send)
@@ -384,7 +398,7 @@ def begin_all_gather_hits_device(hits, qid_base: int = 0, tid_base: int = 0, dev
     rank, world = world_info()
     dev = device if device is not None else torch.device("cpu")
     on_device = hasattr(hits, "copy_to_device") and dev.type == "cuda"
-    if world == 1 or not on_device or id_counts is None or _bits_for(id_counts[0]) + _bits_for(id_counts[1]) > 48:
+    if not _multi(world) or not on_device or id_counts is None or _bits_for(id_counts[0]) + _bits_for(id_counts[1]) > 48:
         return PendingGather(result=all_gather_hits_device(hits, qid_base, tid_base, device, sharded, order, id_counts))
     dist = _dist()
     n_local = int(hits.count)
