@@ -875,6 +875,11 @@ def main():
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
+    else:
+        # before the process group: a rank waiting in init_process_group for a rank 0 that is still compiling would run into
+        # that call's short timeout (normally the library travelled with the snapshot and nobody builds or waits)
+        from kmerseek_amd import build as ks_build
+        ks_build.wait_until_built()
     env = Env(args)
     if env.world > 1:
         env.barrier()  # the other ranks load the library rank 0 has just (re)built

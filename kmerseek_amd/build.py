@@ -34,11 +34,30 @@ def build(force: bool = False, verbose: bool = False, defs=(), out: str = SO) ->
     if not force and not defs and out == SO and not stale():
         return SO
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [HIPCC] + FLAGS + [f"-D{d}" for d in defs] + ["-o", out] + srcs
+    tmp = f"{out}.tmp.{os.getpid()}"  # (linked beside the target and renamed: nobody ever sees half a library, see wait_until_built)
+    cmd = [HIPCC] + FLAGS + [f"-D{d}" for d in defs] + ["-o", tmp] + srcs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd, cwd=CSRC)
+    try:
+        subprocess.check_call(cmd, cwd=CSRC)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return out
+
+
+def wait_until_built(timeout_s: float = 900.0, poll_s: float = 0.5) -> str:
+    """For the ranks of a multi-process job that do NOT build: returns once the library is up to date (at once when it
+    travelled with the snapshot), raises after `timeout_s`.  Rank 0 builds before it joins the process group; a rank that waited
+    for it inside `init_process_group` would run into that call's (deliberately short) timeout instead."""
+    import time
+    t0 = time.time()
+    while stale():
+        if time.time() - t0 > timeout_s:
+            raise TimeoutError(f"{SO} was not (re)built within {timeout_s:.0f} s")
+        time.sleep(poll_s)
+    return SO
 
 
 if __name__ == "__main__":

@@ -162,3 +162,21 @@ def test_synth_is_deterministic():
     to, tm, ta = oracle.sketch_batch(r1, o1, 10, 1, "protein")
     qid, tid, isect, nw = oracle.manysearch(qo, qm, to, tm, ta, n_threads=4)
     assert len(set(qid.tolist())) >= 55 and isect.max() > 20
+
+
+def test_ranks_that_do_not_build_wait_for_the_library(monkeypatch):
+    """bench.py: rank 0 builds before it joins the process group, the other ranks wait for an up-to-date library (not inside
+    init_process_group, whose timeout is short on purpose)."""
+    from kmerseek_amd import build as ks_build
+    so = ks_build.build()
+    assert ks_build.wait_until_built(timeout_s=1.0) == so  # up to date: returns at once
+    state = {"n": 0}
+
+    def stale_twice():
+        state["n"] += 1
+        return state["n"] <= 2
+    monkeypatch.setattr(ks_build, "stale", stale_twice)
+    assert ks_build.wait_until_built(timeout_s=5.0, poll_s=0.01) == so and state["n"] == 3
+    monkeypatch.setattr(ks_build, "stale", lambda: True)
+    with pytest.raises(TimeoutError):
+        ks_build.wait_until_built(timeout_s=0.05, poll_s=0.01)
