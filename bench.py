@@ -145,6 +145,13 @@ class Env:
                 torch.cuda.synchronize(self.dev)
                 if int(t[0]) != self.world:
                     raise RuntimeError(f"all_reduce over {self.world} ranks returned {int(t[0])}")
+                # Every rank is up and the backend works: the short timeout has done its job.  From here on a rank may wait in
+                # a collective for rank 0's untimed side work (CPU baseline, side lines, the unsharded search of the gate).
+                try:
+                    from torch.distributed.distributed_c10d import _set_pg_timeout
+                    _set_pg_timeout(timedelta(seconds=int(os.environ.get("KS_BENCH_RUN_TIMEOUT_S", "900"))))
+                except Exception as e:  # (an older torch: the short timeout stays)
+                    sys.stderr.write(f"[bench] process-group timeout left at {tmo.total_seconds():.0f} s: {e!r}\n")
             except BaseException as e:  # (a plain exit of this child process with a non-zero code; never a re-exec)
                 sys.stderr.write(f"[bench rank {self.rank}/{self.world} device cuda:{self.dev_index} backend {self.backend} "
                                  f"MASTER {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}] {what} failed within "
