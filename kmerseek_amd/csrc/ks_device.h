@@ -5,7 +5,18 @@
 
 #define KS_DEV __device__ __forceinline__
 
-KS_DEV u64 ks_rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }
+// rotl by a compile-time count, as the two v_alignbit_b32 it is (the generic shift / or form costs four instructions here)
+KS_DEV u64 ks_rotl64(u64 x, int r) {
+#ifndef KS_NO_OPAQUE
+    if (__builtin_constant_p(r) && r > 0 && r < 64 && r != 32) {
+        const u32 lo = (u32)x, hi = (u32)(x >> 32);
+        const u32 s = (u32)(r < 32 ? 32 - r : 64 - r);
+        const u32 a = __builtin_amdgcn_alignbit(lo, hi, s), b = __builtin_amdgcn_alignbit(hi, lo, s);
+        return r < 32 ? (((u64)b << 32) | a) : (((u64)a << 32) | b);
+    }
+#endif
+    return (x << r) | (x >> (64 - r));
+}
 
 KS_DEV u64 ks_fmix64(u64 k) {
     k ^= k >> 33;
@@ -19,21 +30,42 @@ KS_DEV u64 ks_fmix64(u64 k) {
 #define KS_C1 0x87c37b91114253d5ULL
 #define KS_C2 0x4cf5ad432745937fULL
 
+// A product that is rotated next: the compiler folds the rotation's left shift into the multiplication — rotl(x * c, 31) becomes
+// (x * (c << 31)) | ((x * c) >> 33), five 32-bit multiplies (half-rate instructions on gfx950: tools/gpu/valu_rates.hip) where
+// three and two v_alignbit do.  An empty asm statement hides the product from that rewrite; it costs no instruction.
+#ifndef KS_NO_OPAQUE
+#define KS_OPAQUE64(x) asm("" : "+v"(x))
+#else
+#define KS_OPAQUE64(x) do { } while (0)
+#endif
+
 // Streaming state of MurmurHash3_x64_128 (both lanes seeded), as sourmash::_hash_murmur uses it
 // (reference call site src/rust/index.rs:766; add_protein via src/rust/signature.rs:274).
 struct ks_murmur {
     u64 h1, h2;
     KS_DEV void init(u64 seed) { h1 = seed; h2 = seed; }
     KS_DEV void block(u64 k1, u64 k2) {
-        k1 *= KS_C1; k1 = ks_rotl64(k1, 31); k1 *= KS_C2; h1 ^= k1;
+        k1 *= KS_C1; KS_OPAQUE64(k1); k1 = ks_rotl64(k1, 31); k1 *= KS_C2; h1 ^= k1;
         h1 = ks_rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ULL;
-        k2 *= KS_C2; k2 = ks_rotl64(k2, 33); k2 *= KS_C1; h2 ^= k2;
+        k2 *= KS_C2; KS_OPAQUE64(k2); k2 = ks_rotl64(k2, 33); k2 *= KS_C1; h2 ^= k2;
         h2 = ks_rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ULL;
     }
     // tail: k1 = bytes 0..7 (already masked), k2 = bytes 8..14 (already masked); t = len & 15
     KS_DEV void tail(u64 k1, u64 k2, u32 t) {
-        if (t > 8) { k2 *= KS_C2; k2 = ks_rotl64(k2, 33); k2 *= KS_C1; h2 ^= k2; }
-        if (t > 0) { k1 *= KS_C1; k1 = ks_rotl64(k1, 31); k1 *= KS_C2; h1 ^= k1; }
+        if (t > 8) {
+#ifndef KS_NO_OPAQUE
+            if (__builtin_constant_p(t) && t <= 12) { // a tail of <= 4 bytes behind the first word: 32 x 64 bits = one v_mad_u64_u32, one v_mul_lo_u32, one add
+                const u32 x = (u32)k2;
+                u64 p = (u64)x * (u32)KS_C2;
+                u32 xh = x * (u32)(KS_C2 >> 32);
+                asm("" : "+v"(xh)); // (keeps the compiler from re-fusing the two into a chain of two v_mad_u64_u32 with moves between them)
+                k2 = p + ((u64)xh << 32);
+            } else
+#endif
+            k2 *= KS_C2;
+            KS_OPAQUE64(k2); k2 = ks_rotl64(k2, 33); k2 *= KS_C1; h2 ^= k2;
+        }
+        if (t > 0) { k1 *= KS_C1; KS_OPAQUE64(k1); k1 = ks_rotl64(k1, 31); k1 *= KS_C2; h1 ^= k1; }
     }
     KS_DEV u64 finish(u64 len) {
         h1 ^= len; h2 ^= len;
@@ -48,7 +80,18 @@ struct ks_murmur {
 template <int I>
 KS_DEV u64 ks_funnel(u64 a, u64 b) {
     if constexpr (I == 0) return a;
+#ifndef KS_NO_OPAQUE
+    else { // on the 32-bit words: two v_alignbyte_b32 at most (the 64-bit shift / or form takes three or four instructions)
+        const u32 w0 = (u32)a, w1 = (u32)(a >> 32), w2 = (u32)b, w3 = (u32)(b >> 32);
+        u32 lo, hi;
+        if constexpr (I < 4) { lo = __builtin_amdgcn_alignbyte(w1, w0, (u32)I); hi = __builtin_amdgcn_alignbyte(w2, w1, (u32)I); }
+        else if constexpr (I == 4) { lo = w1; hi = w2; }
+        else { lo = __builtin_amdgcn_alignbyte(w2, w1, (u32)(I - 4)); hi = __builtin_amdgcn_alignbyte(w3, w2, (u32)(I - 4)); }
+        return ((u64)hi << 32) | lo;
+    }
+#else
     else return (a >> (8 * I)) | (b << (64 - 8 * I));
+#endif
 }
 
 KS_DEV u64 ks_funnel_rt(u64 a, u64 b, u32 byte_shift) {

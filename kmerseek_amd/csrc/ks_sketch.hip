@@ -681,10 +681,17 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         // vector ALU is what the workgroup waits for and the LDS idles.  A tile without repeats (nearly all) then emits its
         // postings straight from these window-order registers: no sequence lookup, no counting phase of its own.
         if (early) {
+            if (A.part_kshift) { // (uniform; decided once, not per window: the digit is a shift at scaled = 1)
 #pragma unroll
-            for (int i = 0; i < SK_E; i++)
-                if (bo[i] != 0xffffffffu)
-                    rkp[i >> 1] |= atomicAdd(&bins[sk_digit(h[i], A.part_K, A.part_kshift, A.part_mask)], 1u) << ((i & 1) * 16); // < SK_TILE
+                for (int i = 0; i < SK_E; i++)
+                    if (bo[i] != 0xffffffffu)
+                        rkp[i >> 1] |= atomicAdd(&bins[((u32)(h[i] >> 32) >> A.part_kshift) & A.part_mask], 1u) << ((i & 1) * 16); // < SK_TILE
+            } else {
+#pragma unroll
+                for (int i = 0; i < SK_E; i++)
+                    if (bo[i] != 0xffffffffu)
+                        rkp[i >> 1] |= atomicAdd(&bins[__umulhi((u32)(h[i] >> 32), A.part_K) & A.part_mask], 1u) << ((i & 1) * 16);
+            }
         }
     } else {
 #pragma unroll
