@@ -372,50 +372,61 @@ __global__ __launch_bounds__(256) void k_tile_plan(const u64 *offs, u32 n_seqs, 
     tile_first[t] = t == n_tiles ? n_seqs : sk_lower_bound(offs, 0, n_seqs, (u64)t * R);
 }
 
-// Compacting variant, windows [p0 + H, p0 + H + 4) of a thread: hash, keep what passes the threshold, append to the LDS list
+// Compacting variant, windows [p0 + H, p0 + H + NW) of a thread: hash, keep what passes the threshold, append to the LDS list
 // (hash -> hlist, sequence relative to the tile's first -> slist): wave scan of the per-lane keep counts, one LDS atomic
 // per wave.  Entries beyond SK_TILE are dropped (the cursor keeps counting: the tile then reports the overflow).
-template <int H, int KC>
+template <int H, int NW, int KC>
 KS_DEV void sk_cmp_half(const sk_args &A, const sk_bounds &B, sk_seq &q, const u64 *wl, u32 p0, bool active, u32 s_first, u32 s_end,
                         u32 lane, u64 *hlist, u8 *slist, u32 *cursor) {
-    u64 h[4];
-    u32 keep = 0, sr = 0; // keep mask of the 4 windows, their sequences (one byte each)
+    static_assert(NW == 4 || NW == 8, "a half or the whole of a thread's windows");
+    u64 h[NW];
+    u32 keep = 0, sr[2] = {0, 0}; // keep mask of the NW windows, their sequences (one byte each)
     if (active) {
         h[0] = sk_hash_window<H + 0, KC>(wl, A.k, A.seed);
         h[1] = sk_hash_window<H + 1, KC>(wl, A.k, A.seed);
         h[2] = sk_hash_window<H + 2, KC>(wl, A.k, A.seed);
         h[3] = sk_hash_window<H + 3, KC>(wl, A.k, A.seed);
+        if constexpr (NW == 8) {
+            h[4] = sk_hash_window<H + 4, KC>(wl, A.k, A.seed);
+            h[5] = sk_hash_window<H + 5, KC>(wl, A.k, A.seed);
+            h[6] = sk_hash_window<H + 6, KC>(wl, A.k, A.seed);
+            h[7] = sk_hash_window<H + 7, KC>(wl, A.k, A.seed);
+        }
         if ((KC ? (u32)KC : A.k) >= SK_E) { // (uniform) one sequence per thread: sk_place_window_run
             const u32 srel = q.s - s_first;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < NW; i++)
                 if ((p0 + H + i - q.ls) < q.nw && h[i] != 0 && h[i] <= A.max_hash) keep |= 1u << i;
-            sr = srel * 0x01010101u;
+            sr[0] = sr[1] = srel * 0x01010101u;
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NW; i++) {
                 const u32 p = p0 + H + i;
                 while (q.s < s_end && p >= q.le) { q.s++; sk_load_seq(q, A, B, s_end); }
                 if (q.ok && p >= q.ls && p + A.k <= q.le && h[i] != 0 && h[i] <= A.max_hash) {
                     keep |= 1u << i;
-                    sr |= (q.s - s_first) << (8 * i);
+                    sr[i >> 2] |= (q.s - s_first) << (8 * (i & 3));
                 }
             }
         }
     }
     const u32 nk = (u32)__popc(keep);
     const u32 incl = ks_wave_incl_scan(nk);
-    const u32 wtot = __shfl(incl, 63, 64);
+    // (the wave's total and its slice of the list travel through scalar registers — v_readlane / v_readfirstlane —, not through
+    // two ds_bpermute round trips per half and sub-tile)
+    const u32 wtot = (u32)__builtin_amdgcn_readlane((int)incl, 63);
     u32 wbase = 0;
-    if (lane == 63 && wtot) wbase = atomicAdd(cursor, wtot);
-    wbase = __shfl(wbase, 63, 64);
+    if (wtot) { // (uniform)
+        if (lane == 0) wbase = atomicAdd(cursor, wtot);
+        wbase = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
+    }
     u32 pos = wbase + incl - nk;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NW; i++)
         if (keep & (1u << i)) {
             if (pos < SK_TILE) {
                 hlist[pos] = h[i];
-                slist[pos] = (u8)(sr >> (8 * i));
+                slist[pos] = (u8)(sr[i >> 2] >> (8 * (i & 3)));
             }
             pos++;
         }
@@ -593,6 +604,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                 if (tid < NCH) stage_chunk(rv);
                 __syncthreads();
             }
+            SK_STAMP_AT(9); // (stamps 9 .. 11: the compacting loop's stage / hash + append / closing barrier)
             if (sub + 1 < n_sub && tid < NCH) // next sub-tile's residues travel while this one is hashed
                 rv = load_chunk((u64)tile * A.R + (u64)(sub + 1) * SK_TILE + (u64)tid * 16);
             const u32 p0 = sub * SK_TILE + q0;
@@ -607,10 +619,18 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                 q.s = lo;
                 sk_load_seq(q, A, B, s_end);
             }
-            // two halves of 4 windows: 8 live hashes next to the prefetched residues do not fit the register budget
-            sk_cmp_half<0, KC>(A, B, q, wl, p0, active, s_first, s_end, lane, tmp, slist, &n_list_s);
-            sk_cmp_half<4, KC>(A, B, q, wl, p0, active, s_first, s_end, lane, tmp, slist, &n_list_s);
+            // all eight windows behind one scan and one cursor atomic where the eight live hashes fit the register budget next to
+            // the prefetched residues (k = 16: 75 registers, configs[2] launch 0.147 -> 0.143 ms); two halves of four otherwise
+            // (k = 24 spills 56 bytes with eight and is 4 % slower)
+            if constexpr (KC == 16) {
+                sk_cmp_half<0, 8, KC>(A, B, q, wl, p0, active, s_first, s_end, lane, tmp, slist, &n_list_s);
+            } else {
+                sk_cmp_half<0, 4, KC>(A, B, q, wl, p0, active, s_first, s_end, lane, tmp, slist, &n_list_s);
+                sk_cmp_half<4, 4, KC>(A, B, q, wl, p0, active, s_first, s_end, lane, tmp, slist, &n_list_s);
+            }
+            SK_STAMP_AT(10);
             __syncthreads(); // the sub-tile is hashed (its residues may be overwritten) and its appends are visible
+            SK_STAMP_AT(11);
         }
         const u32 n_list = n_list_s;
         if (!B.in_lds || n_list > SK_TILE) {
@@ -711,19 +731,19 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         }
     }
     // ---- phase 3: bucket counts -> bucket starts (exclusive scan over the tile).  The thread that scans a bucket knows its
-    // size: buckets that hold more than one hash are LISTED here and put in order in place by phase 5 — nothing is ranked
+    // size: buckets that hold more than TWO hashes are LISTED here and put in order in place by phase 5 — nothing is ranked
     // element by element (that cost as much as hashing: 812 VALU instructions per wave against 796, profiles/r02_sq_counters.md).
     // The lists live in the residue buffer, dead since the hash phase (the compacting variant keeps its bucket table in
     // the first 8 bytes per sequence of it): 16-bit entries; qb = buckets of more than SK_C3MAX (never more than
-    // SK_TILE / (SK_C3MAX + 1) of them), q3 = buckets of 3 .. SK_C3MAX, q2 = pairs (entry = the pair's first position).
+    // SK_TILE / (SK_C3MAX + 1) of them), q3 = buckets of 3 .. SK_C3MAX.  Pairs stay with the thread that scanned them (`pairs`).
     const u32 q_skip = CMP ? 2u * (ns < SK_SEQ_CAP + 1u ? ns : SK_SEQ_CAP + 1u) : 0u; // (8 bytes of bucket table per sequence)
     u16 *qb = (u16 *)((u32 *)res_w + q_skip);
     u16 *q3 = qb + SK_QB_CAP;
     const u32 q_ents = ((SK_TILE + SK_PAD) / 4 - q_skip) * 2 - SK_QB_CAP;
-    u32 q3cap = q_ents * 2 / 5, q2cap = q_ents - q3cap;
-    u16 *q2 = q3 + q3cap;
-    if (A.debug_qcap) { q2cap = q2cap < A.debug_qcap ? q2cap : A.debug_qcap; q3cap = q3cap < A.debug_qcap ? q3cap : A.debug_qcap; } // (tests: full lists)
+    u32 q3cap = q_ents;
+    if (A.debug_qcap) q3cap = q3cap < A.debug_qcap ? q3cap : A.debug_qcap; // (tests: full lists)
     u32 ovf = 0; // my buckets that found no room in a list (bit layout of the class masks below): I put them in order myself
+    u32 pairs = 0; // my buckets that hold exactly two hashes (same bit layout): put in order by me in phase 5
     {
         const uint4 w4 = *(const uint4 *)&cnt[q0 >> 1]; // 8 consecutive 16-bit counters
         const u32 w[4] = {w4.x, w4.y, w4.z, w4.w};
@@ -742,10 +762,14 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             for (int j = 0; j < 4; j++) big |= (((w[j] + (0x8000u - SK_C3MAX - 1u) * 0x00010001u) & 0x80008000u) >> 15) << j;
         }
         u32 m2 = ge2 & ~ge3, m3 = ge3 & ~big;
-        const u32 code = (u32)__popc(m2) | ((u32)__popc(m3) << 12) | ((u32)__popc(big) << 24); // (tile totals fit the fields)
+        // Pairs (18 % of the buckets, 1.5 per thread) are NOT listed: listing them cost more than it balanced — a loop of ~18 vector
+        // instructions per pair that every wave runs as often as its fullest lane (4 - 5 times), plus the list's own pass in
+        // phase 5 —; their owner keeps this mask and swaps them in place in phase 5, 8 predicated steps without a loop.
+        pairs = m2;
+        const u32 code = ((u32)__popc(m3) << 12) | ((u32)__popc(big) << 24); // (tile totals fit the fields)
         u32 total, at;
         u32 ex = sk_block_excl_scan2(s, code, scan_smem, &total, &at);
-        u32 i2 = at & 0xfffu, i3 = (at >> 12) & 0xfffu, ib = at >> 24;
+        u32 i3 = (at >> 12) & 0xfffu, ib = at >> 24;
         u32 o[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) { // starts <= 4096 fit 16 bits
@@ -755,14 +779,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         }
         *(uint4 *)&cnt[q0 >> 1] = make_uint4(o[0], o[1], o[2], o[3]);
         if (tid == SK_THREADS - 1) cnt[SK_TILE / 2] = total | (total << 16);
-        // list entries: the first position of a pair; bucket numbers otherwise
-        while (m2) {
-            const u32 bit = (u32)__builtin_ctz(m2);
-            m2 &= m2 - 1u;
-            const u32 j = bit & 15u, wsel = j == 0 ? o[0] : (j == 1 ? o[1] : (j == 2 ? o[2] : o[3]));
-            if (i2 < q2cap) q2[i2] = (u16)((wsel >> (bit & 16u)) & 0xffffu); else ovf |= 1u << bit; // the pair's first position
-            i2++;
-        }
+        // list entries: bucket numbers
         while (m3) {
             const u32 bit = (u32)__builtin_ctz(m3);
             m3 &= m3 - 1u;
@@ -829,16 +846,24 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     };
     {
         const u32 qc = scan_smem[SK_THREADS / 64]; // list totals, left there by phase 3's scan
-        const u32 n2 = (qc & 0xfffu) < q2cap ? (qc & 0xfffu) : q2cap;
         const u32 n3 = ((qc >> 12) & 0xfffu) < q3cap ? ((qc >> 12) & 0xfffu) : q3cap;
         const u32 nb = qc >> 24;
-        for (u32 e = tid; e < n2; e += SK_THREADS) {
-            const u32 sb = q2[e];
-            const u64 x = tmp[sb], y = tmp[sb + 1];
-            if (x > y) { tmp[sb] = y; tmp[sb + 1] = x; }
-            nd += x == y ? 1u : 0u;
+        { // my pairs: the starts of my 8 buckets are where phase 3 left them (16 bits each)
+            const uint4 st4 = *(const uint4 *)&cnt[q0 >> 1];
+            const u32 st[4] = {st4.x, st4.y, st4.z, st4.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 stj = st[j];
+#pragma unroll
+                for (int hh = 0; hh < 2; hh++)
+                    if (pairs & (1u << (j + 16 * hh))) {
+                        const u32 sb = hh ? stj >> 16 : stj & 0xffffu;
+                        const u64 x = tmp[sb], y = tmp[sb + 1];
+                        if (x > y) { tmp[sb] = y; tmp[sb + 1] = x; }
+                        nd += x == y ? 1u : 0u;
+                    }
+            }
         }
-        // (from the last thread down: the waves a second round of pairs keeps busy are the first ones)
         for (u32 e = SK_THREADS - 1u - tid; e < n3; e += SK_THREADS) {
             const u32 b = q3[e], sb = bstart(b);
             sort_small(sb, bstart(b + 1) - sb);
@@ -1239,6 +1264,9 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         // (Measured, round 4: four of a thread's rounds at once — four LDS reads in flight, then eight stores back to back — made
         // the query launch 4 % SLOWER, and the same unrolling of the posting stores 1.5 %: bursts of stores delay the loads and
         // atomics other workgroups of the CU are waiting for.  One element per round it stays.)
+        // (Measured, round 4: a separate loop for the common tile — no repeats, no deferred sequence: scalar base pointers, 32-bit
+        // offsets, ~45 instead of ~106 vector instructions per wave — made the query launch 1.5 % SLOWER: the stores leave in a
+        // tighter burst, and two more scalar registers spilled.)
         for (u32 d = tid; d < ((!B.in_lds && any_dup) ? 0u : n_distinct); d += SK_THREADS) {
             u64 pos = base + d;
             if (!any_dup) { // (uniform) distinct rank == kept rank: the run leaves as it lies

@@ -5,12 +5,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-#define N_ITER 2048
+#define N_ITER 8192
 #define CHAINS 8
 
 template <int OP>
@@ -43,6 +44,13 @@ __global__ __launch_bounds__(256) void k_rate(u32 *out, u32 seed, u32 c_in) {
             if (OP == 16) asm volatile("v_pk_mad_u16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(b[(i + 1) % CHAINS]));
             if (OP == 17) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(w[i]) : "v"(w[(i + 1) % CHAINS]));
             if (OP == 18) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(w[i]) : "v"(w[(i + 1) % CHAINS]));
+            if (OP == 19) asm volatile("v_xor_b32_e64 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            if (OP == 20) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            if (OP == 21) asm volatile("v_lshrrev_b32_e32 %0, 1, %0" : "+v"(a[i]));
+            if (OP == 22) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "s"(c), "v"(b[i]));
+            if (OP == 23) asm volatile("v_add_co_u32_e32 %0, vcc, %0, %1\n\tv_addc_co_u32_e32 %2, vcc, %2, %1, vcc" : "+v"(a[i]), "+v"(b[i]), "+v"(b[(i + 1) % CHAINS]) : : "vcc");
+            if (OP == 24) asm volatile("v_xor_b32_e32 %0, 0x12345678, %0" : "+v"(a[i])); // VOP2 + 32-bit literal (8 bytes)
+            if (OP == 26) asm volatile("v_xor_b32_e32 %0, %0, %1\n\tv_mul_lo_u32 %2, %2, %3\n\tv_xor_b32_e32 %1, %1, %0" : "+v"(a[i]), "+v"(b[i]), "+v"(b[(i + 1) % CHAINS]) : "s"(c)); // 2 VOP2 + 1 VOP3
         }
     }
     u32 r = 0;
@@ -56,7 +64,7 @@ static void run(const char *name, int n_instr_per_slot, u32 *d_out) {
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
-    const int blocks = cus * 8; // 8 workgroups of 4 waves per CU = 8 waves per SIMD
+    const int blocks = cus * (getenv("WPS") ? atoi(getenv("WPS")) : 8); // workgroups of 4 waves per CU = waves per SIMD (WPS)
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k_rate<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 1u, 12345u);
@@ -96,5 +104,12 @@ int main() {
     run<16>("v_pk_mad_u16", 1, d_out);
     run<17>("v_mul_f64", 1, d_out);
     run<18>("v_fma_f64", 1, d_out);
+    run<19>("v_xor_b32_e64 (VOP3)", 1, d_out);
+    run<20>("v_add_u32_e32", 1, d_out);
+    run<21>("v_lshrrev_b32_e32", 1, d_out);
+    run<22>("v_and_or_b32", 1, d_out);
+    run<23>("v_add_co + v_addc (VOP2 x2)", 2, d_out);
+    run<24>("v_xor_b32_e32 + literal", 1, d_out);
+    run<26>("2 x v_xor_e32 + v_mul_lo", 3, d_out);
     return 0;
 }

@@ -59,7 +59,7 @@ def child(args):
         buf = (ctypes.c_ulonglong * 16)()
         L.ks_debug_read_stamps(buf, 0)
         tot = float(sum(buf)) or 1.0
-        out["sketch_phase_share"] = [round(v / tot, 4) for v in buf[:9]]
+        out["sketch_phase_share"] = [round(v / tot, 4) for v in buf[:12]]
     if hasattr(L, "ks_debug_read_join_stamps"):
         buf = (ctypes.c_ulonglong * 16)()
         L.ks_debug_read_join_stamps(buf, 0)
