@@ -198,7 +198,10 @@ done:
 #define JN_WLIST 128
 #endif
 #ifndef JN_FILLU
-#define JN_FILLU 6
+#define JN_FILLU 10 // index fingerprints per thread and staging round (fingerprint join): 5,120 per round — a bucket of ~4.5k in ONE round trip
+#endif
+#ifndef JK_FILLU
+#define JK_FILLU 6  // index keys (64 bits) per thread and staging round (key-column join)
 #endif
 #ifndef JN_CAP
 #define JN_CAP 6144
@@ -315,17 +318,17 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_buckets_keys(const u64 *qke
     }
     for (u64 c0 = ts; c0 < te; c0 += JN_CAP_KEYS) {
         const u32 n = (u32)((te - c0) < JN_CAP_KEYS ? (te - c0) : JN_CAP_KEYS);
-        // JN_FILLU loads of a thread are in flight before their LDS stores (a plain loop waits out one memory latency
+        // JK_FILLU loads of a thread are in flight before their LDS stores (a plain loop waits out one memory latency
         // per 512 keys; all JN_CAP / JN_THREADS at once costs the registers of a third workgroup per CU)
-        for (u32 i0 = 0; i0 < n; i0 += JN_THREADS * JN_FILLU) {
-            u64 kk[JN_FILLU];
+        for (u32 i0 = 0; i0 < n; i0 += JN_THREADS * JK_FILLU) {
+            u64 kk[JK_FILLU];
 #pragma unroll
-            for (int j = 0; j < JN_FILLU; j++) {
+            for (int j = 0; j < JK_FILLU; j++) {
                 const u32 i = i0 + (u32)j * JN_THREADS + tid;
                 kk[j] = i < n ? ikeys[c0 + i] : 0;
             }
 #pragma unroll
-            for (int j = 0; j < JN_FILLU; j++) {
+            for (int j = 0; j < JK_FILLU; j++) {
                 const u32 i = i0 + (u32)j * JN_THREADS + tid;
                 if (i < n) lk[i] = kk[j];
             }
@@ -578,15 +581,18 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
 #ifdef JN_STAMP
     unsigned long long jn_t_prev = clock64();
 #endif
-    const u64 qs = q_lo[blockIdx.x], qe = q_hi[blockIdx.x]; // dense postings: q_hi = q_lo + 1 (a directory)
-    const u64 ts = dir_t[blockIdx.x], te = dir_t[blockIdx.x + 1];
-    const ks_bmeta bm = bmeta[blockIdx.x]; // (with the directory words: one memory latency)
+    // (Measured, round 4: XCD-contiguous bucket numbers — ks_xcd_block, so that neighbouring buckets' 48 bytes of bucket words come
+    // through one L2 — change nothing: 1.38 - 1.40 ms either way.)
+    const u32 bkt = blockIdx.x;
+    const u64 qs = q_lo[bkt], qe = q_hi[bkt]; // dense postings: q_hi = q_lo + 1 (a directory)
+    const u64 ts = dir_t[bkt], te = dir_t[bkt + 1];
+    const ks_bmeta bm = bmeta[bkt]; // (with the directory words: one memory latency)
     if (qs == qe || ts == te) return;
-    const jn_qfmt<F10> QF(fp_shift, blockIdx.x);
+    const jn_qfmt<F10> QF(fp_shift, bkt);
     // The pair list is cut into seg_mask + 1 segments of `cap` records, each with its own cursor (JN_CUR_STRIDE words apart:
     // different memory channels): atomics on ONE address are served one at a time, ~12 ns each on this chip — 65,536 buckets
     // on one cursor are 0.8 ms of queueing whatever else the kernel does.  A bucket appends to segment (bucket mod segments).
-    const u32 seg = blockIdx.x & seg_mask;
+    const u32 seg = bkt & seg_mask;
     unsigned long long *cursor = cursors + (size_t)seg * JN_CUR_STRIDE;
     pair_keys += (u64)seg * cap;
     if (pair_vals) pair_vals += (u64)seg * cap;
@@ -619,26 +625,31 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
             for (u32 j = s_last + 1u + tid; j <= (u32)JN_DIR; j += JN_THREADS) ldir[j] = (unsigned short)n;
         }
         for (u32 i0 = 0; i0 < n; i0 += JN_THREADS * JN_FILLU) {
-            u32 kk[JN_FILLU], pp[JN_FILLU];
+            u32 kk[JN_FILLU];
 #pragma unroll
             for (int j = 0; j < JN_FILLU; j++) {
                 const u32 i = i0 + (u32)j * JN_THREADS + tid;
                 kk[j] = i < n ? fpc[i] : 0;
-                pp[j] = 0;
-                if (lane == 0 && i < n && i) pp[j] = fpc[i - 1]; // (one lane per wave: its left neighbour sits in the wave before)
             }
-            // (the fingerprint before mine: consecutive threads hold consecutive fingerprints, so it comes from the lane below —
-            // round 3 loaded it a second time, 9 more global loads per thread: join 1.42 -> 1.40 ms)
-#pragma unroll
-            for (int j = 0; j < JN_FILLU; j++) { const u32 b = ks_lane_below(kk[j]); pp[j] = lane ? b : pp[j]; }
+            // The fingerprint before mine: consecutive threads hold consecutive fingerprints, so it comes from the lane below (round 3
+            // loaded it a second time, 9 more global loads per thread: join 1.42 -> 1.40 ms); lane 0's sits in the wave before: lane j
+            // of the wave loads it for slot j — ONE register for all slots instead of one per slot, which is what lets JN_FILLU
+            // slots be in flight at once within the register budget (a bucket's ~4.5k fingerprints in one round trip, not two).
+            u32 ppx = 0;
+            {
+                const u32 iw = i0 + lane * JN_THREADS + (tid & ~63u); // lane j: where this wave's slot j starts
+                if (lane < (u32)JN_FILLU && iw < n && iw) ppx = fpc[iw - 1];
+            }
 #pragma unroll
             for (int j = 0; j < JN_FILLU; j++) {
                 const u32 i = i0 + (u32)j * JN_THREADS + tid;
+                const u32 below = ks_lane_below(kk[j]);
+                const u32 first = (u32)__builtin_amdgcn_readlane((int)ppx, j);
                 if (i < n) {
                     lk[i] = kk[j];
                     if (i) {
                         const u32 sa = jn_slot(kk[j], dirM);
-                        for (u32 sl = jn_slot(pp[j], dirM) + 1u; sl <= sa; sl++) ldir[sl] = (unsigned short)i;
+                        for (u32 sl = jn_slot(lane ? below : first, dirM) + 1u; sl <= sa; sl++) ldir[sl] = (unsigned short)i;
                     }
                 }
             }
@@ -861,12 +872,13 @@ __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8
     __shared__ u32 wcount[JS_THREADS / 64];
     __shared__ u32 scan_smem[JS_THREADS / 64 + 1];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const u64 qs = q_lo[blockIdx.x], qe = q_hi[blockIdx.x];
-    const u64 ts = dir_t[blockIdx.x], te = dir_t[blockIdx.x + 1];
-    const ks_bmeta bm = bmeta[blockIdx.x];
+    const u32 bkt = blockIdx.x;
+    const u64 qs = q_lo[bkt], qe = q_hi[bkt];
+    const u64 ts = dir_t[bkt], te = dir_t[bkt + 1];
+    const ks_bmeta bm = bmeta[bkt];
     if (qs == qe || ts == te) return;
-    const jn_qfmt<F10> QF(fp_shift, blockIdx.x);
-    const u32 seg = blockIdx.x & seg_mask;
+    const jn_qfmt<F10> QF(fp_shift, bkt);
+    const u32 seg = bkt & seg_mask;
     unsigned long long *cursor = cursors + (size_t)seg * JN_CUR_STRIDE;
     pair_keys += (u64)seg * cap;
     if (pair_vals) pair_vals += (u64)seg * cap;
