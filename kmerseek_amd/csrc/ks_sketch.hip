@@ -1114,6 +1114,9 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                 qrel[pos] = (u16)((srl[i >> 2] >> (8 * (i & 3))) & 0xffu);
             }
         __syncthreads();
+        // (Measured, round 4: the 16-bit value column four entries per store — groups of four consecutive elements inside one digit's
+        // run have four consecutive slots: one 8-byte store at a 2-byte aligned address instead of four 2-byte stores — made the
+        // query launch 3 % SLOWER (2.22 -> 2.29 ms): the unaligned stores split, and the column needs a loop of its own.)
         for (u32 i = tid; i < n_distinct; i += SK_THREADS) {
             const u64 hh = tmp[i];
             const u64 at = gaddr[sk_digit(hh, A.part_K, A.part_kshift, A.part_mask)] + i;
