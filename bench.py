@@ -513,18 +513,22 @@ def run_queries_sharded(args, env, ks, synth, ksd):
             r["posting_bytes"] = pb
             r["bucket_posting_bytes"] = bb
             r["achieved_incl_fused_scratch"] = (b + pb * n_q_hashes) / avg_s / 1e9
-            # What this kernel actually runs against (informational; `bound` stays the contract's "hbm"): the vector ALU.  The
-            # hash alone is ~75 plain + 24 half-rate (32-bit multiply: aux.device.u64_gmul_per_s_measured) instructions per
-            # window at k = 10 (ISA of k_sketch_tiles<0, 0, 10>; profiles/README.md): 123 quad-cycles per 64 windows and SIMD.
+            # What this kernel actually runs against (informational; `bound` stays the contract's "hbm"): the vector ALU.  Every
+            # wave of the query launch issues ~1,620 vector instructions (phase ladder of round 4, DESIGN.md 3.1: hash + placement
+            # 613, scan 235 -> ~170, scatter 62, ordering 131, look-back + offsets 80, CSR write 106, postings 318); on gfx950 a SIMD
+            # issues one wave64 instruction per ~4.4 cycles whether it is a 32-bit multiply, v_mad_u64_u32 or a three-operand
+            # add (tools/gpu/valu_rates.hip: multiplies are FULL rate — rounds 2-4 priced them at half rate), ~2.4 for two-operand ops.
             if (k, scaled, mol) == (10, 1, "protein"):
                 props = torch.cuda.get_device_properties(env.dev)
                 simds, clk = props.multi_processor_count * 4, 2.4e9
-                floor_s = (q_windows / 64.0) * 123 * 4 / simds / clk
-                r["valu_model"] = {"hash_quad_cycles_per_64_windows": 123, "simds": simds, "clock_hz_assumed": clk,
-                                   "hash_only_floor_ms": floor_s * 1e3, "launch_over_hash_floor": avg_s / floor_s,
-                                   "note": "SQ counters: 1,686 vector instructions per wave of which ~200 are half-rate multiplies (profiles/r04_sq_counters.md); "
-                                           "diagnostic builds without stores and look-back run the launch in 1.91 ms (DESIGN.md 3.1): the rest is the "
-                                           "chain of phases and the stores, not vector issue"}
+                waves = 8.0 * (n_q / 12.7)  # ~12.7 proteins per packed tile, 8 waves per tile (629k waves per 1M proteins)
+                floor_s = waves * 1620 * 4.0 / simds / clk
+                r["valu_model"] = {"vector_instructions_per_wave": 1620, "cycles_per_instruction_assumed": 4.0, "simds": simds,
+                                   "clock_hz_assumed": clk, "waves_estimated": waves,
+                                   "vector_issue_floor_ms": floor_s * 1e3, "launch_over_vector_issue_floor": avg_s / floor_s,
+                                   "note": "SQ counters: ~1,620 vector instructions per wave, all full rate (tools/gpu/valu_rates.hip); six waves per SIMD keep "
+                                           "the vector ALU ~80 % issued (profiles/r04_sq_counters.md): what the launch has left is instructions, "
+                                           "at roughly half a per cent of time per per cent of them (measured, DESIGN.md 3.1)"}
         else:
             r["design_bytes_per_launch"] = b
             r["note"] = "scratch pass of the search: bytes it has to move by design, not SURVEY 8(d) algorithmic bytes"
