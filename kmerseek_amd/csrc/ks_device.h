@@ -162,6 +162,27 @@ KS_DEV u32 ks_lane_lt_count(u64 mask) {
     return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0));
 }
 
+// Stable rank of an 8-bit digit inside one wave ("match-any" by eight ballots): returns d << 16 | (records of digit d the wave
+// counted before this round + lanes below mine that hold d), and adds the round's count to the wave's counter wc[d].
+// Per bit: the lane's bit as a mask (v_bfe_i32: 0 / -1), one ballot, and peers &= ~(ballot ^ mask) on each half — a three-input
+// boolean, one v_bitop3_b32 (the generic select form `bit ? m : ~m` compiled to nine vector instructions per bit).  The lowest
+// lane of a group of peers (no peer below it) publishes the new count; EVERY lane reads the old one first — the LDS operations
+// of a wave execute in order, so no lane-to-lane exchange (ds_bpermute) is needed for it.
+KS_DEV u32 ks_match8_rank(u32 d, u32 *wc) {
+    u32 plo = ~0u, phi = ~0u;
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const u32 bm = (u32)__builtin_amdgcn_sbfe((int)d, (u32)b, 1u);
+        const u64 m = __ballot(bm != 0u);
+        plo &= ~((u32)m ^ bm);
+        phi &= ~((u32)(m >> 32) ^ bm);
+    }
+    const u32 below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0));
+    const u32 pre = wc[d];
+    if (below == 0) wc[d] = pre + (u32)__popc(plo) + (u32)__popc(phi);
+    return (d << 16) | (pre + below);
+}
+
 // Join prefix of a kept hash: floor(h * 2^pbits / (max_hash + 1)) computed on the top 32 bits — uniform over
 // [0, 2^pbits) for every `scaled` (kept hashes only span [0, max_hash], so plain top bits are NOT uniform for scaled > 1).
 // K = floor(2^(pbits+32) / ((max_hash >> 32) + 1)); for scaled = 1 this is exactly h >> (64 - pbits).  Monotone in h.

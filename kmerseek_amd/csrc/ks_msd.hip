@@ -189,19 +189,7 @@ KS_DEV void ml_rank(const u64 *key, u32 *rank, u32 nvalid, u32 wloc, u32 lane, u
     for (int r = 0; r < ML_IPT; r++) {
         const u32 li = wloc + (u32)r * 64 + lane;
         const u32 d = li < nvalid ? ((u32)(key[r] >> shift) & mask) : 255u;
-        u64 peers = ~0ULL;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const u64 m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
-        }
-        const u32 below = ks_lane_lt_count(peers);
-        const u32 cnt = (u32)__popcll(peers);
-        const u32 leader = (u32)__ffsll((long long)peers) - 1u;
-        u32 pre = 0;
-        if (lane == leader) { pre = wcnt[wave][d]; wcnt[wave][d] = pre + cnt; }
-        pre = __shfl(pre, (int)leader, 64);
-        rank[r] = (d << 16) | (pre + below);
+        rank[r] = ks_match8_rank(d, wcnt[wave]);
     }
 }
 
@@ -244,18 +232,7 @@ KS_DEV void ml_sort_wave(u64 *keys, u64 s, u32 nb, int lo_bit, int rem_bits, u32
             if (r < nr) { // (a guard, not a break: the loop must unroll or key[] / rank[] leave the registers)
                 const u32 li = (u32)r * 64 + lane;
                 const u32 d = li < nb ? ((u32)(key[r] >> shift) & mask) : 255u;
-                u64 peers = ~0ULL;
-#pragma unroll
-                for (int b = 0; b < 8; b++) {
-                    const u64 m = __ballot((d >> b) & 1u);
-                    peers &= ((d >> b) & 1u) ? m : ~m;
-                }
-                const u32 below = ks_lane_lt_count(peers);
-                const u32 leader = (u32)__ffsll((long long)peers) - 1u;
-                u32 pre = 0;
-                if (lane == leader) { pre = wc[d]; wc[d] = pre + (u32)__popcll(peers); }
-                pre = __shfl(pre, (int)leader, 64);
-                rank[r] = (d << 16) | (pre + below);
+                rank[r] = ks_match8_rank(d, wc);
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -359,20 +359,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
     for (int r = 0; r < RS_IPT; r++) {
         const u32 li = wloc + (u32)r * 64 + lane;
         u32 d = li < nvalid ? ks_rs_digit(key[r], shift, pfxK) : 255u;
-        // lanes holding the same digit
-        u64 peers = ~0ULL;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            u64 m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
-        }
-        u32 below = ks_lane_lt_count(peers);
-        u32 cnt = (u32)__popcll(peers);
-        u32 leader = (u32)__ffsll((long long)peers) - 1u;
-        u32 pre = 0;
-        if (lane == leader) { pre = wcnt[wave][d]; wcnt[wave][d] = pre + cnt; }
-        pre = __shfl(pre, (int)leader, 64);
-        rank[r] = (d << 16) | (pre + below);
+        rank[r] = ks_match8_rank(d, wcnt[wave]); // lanes holding the same digit, in lane order
     }
     __syncthreads();
     // digit-major exclusive offsets: thread d < 256 owns digit d
@@ -817,7 +804,9 @@ static int radix_sort_tagged(ks_ctx *ctx, const u64 *keys_in, const V *vals_in, 
                              u32 pfxK) {
     *keys_out = (u64 *)keys_in;
     *vals_out = (V *)vals_in;
-    if (n <= 1 || n_shifts <= 0) return KS_OK;
+    // nothing to sort: the caller gets its own arrays back (and must not take them for one of the scratch pairs).  A SEGMENTED
+    // input of one record still goes through its passes: the record sits at its region's base, not at index 0.
+    if (n == 0 || n_shifts <= 0 || (n == 1 && !seg)) return KS_OK;
     if (n >= 0xffffffffULL) return ks_fail(ctx, KS_ERR_CAPACITY, "radix sort: %llu records exceed the 32-bit offset range", (unsigned long long)n);
     const u32 nblocks_dense = (u32)((n + RS_TILE - 1) / RS_TILE);
     const u32 tiles_per_seg = seg ? (u32)((seg->cap + RS_TILE - 1) / RS_TILE) : 0;

@@ -105,6 +105,10 @@ int ks_index_build_impl(ks_ctx *ctx, const ks_sketches *t, ks_index **out) {
             hipLaunchKernelGGL(k_split_vals, dim3((u32)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const u64 *)vs, n, ix->d_tids, ix->d_abunds, d_max);
             ks_timer_end(ctx);
             IX_HIP(hipGetLastError());
+            if (ks != k0 && ks != k1) { // (n == 1: nothing to sort, the keys are still the sketch's own array — found by the fuzz campaign)
+                IX_HIP(hipMemcpyAsync(k0, ks, (size_t)n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+                ks = k0;
+            }
             if (ks == k0) { ix->d_keys = k0; k0 = nullptr; } else { ix->d_keys = k1; k1 = nullptr; }
         }
         IX_HIP(hipMemcpyAsync(ctx->h_pin, d_max, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));

@@ -798,6 +798,28 @@ def test_index_build_paths_agree(ctx, monkeypatch, nt, k, scaled, mol):
             assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("targets", [[b"A" * 4080], [b"M", b"A" * 4080], [b"ACDEFGHIKLMNPQRW"], [b"ACDEFGHIKLMNPQRW", b"ACDEFGHIKLMNPQRWY"]])
+def test_index_of_one_or_two_postings_on_both_build_paths(ctx, monkeypatch, targets):
+    """An index of ONE posting (a single-letter sequence: one distinct k-mer, abundance 4065; a sequence of exactly k residues)
+    has nothing to sort: the LSD fallback returned the sketch's own key array and the index then kept an uninitialised buffer
+    (0 hits for 43 expected — round 4's fuzz campaign, seed 5308 case 141).  Both build paths, against the oracle."""
+    t_res, t_off = ks.pack(targets)
+    q_res, q_off = ks.pack([b"A" * 40, b"ACDEFGHIKLMNPQRWYACDEFGHIKLMNPQRW", b"WWWWWWWWWWWWWWWWWWWW", b"A" * 16])
+    for mol in ("protein", "hp"):
+        T = ctx.sketch_batch(t_res, t_off, 16, 1, mol)
+        Q = ctx.sketch_batch(q_res, q_off, 16, 1, mol)
+        to, tm, ta = T.to_host()
+        qo, qm, _ = Q.to_host()
+        want = oracle.manysearch(qo, qm, to, tm, ta, n_threads=2)
+        a = ctx.search(ctx.index_build(T), Q).to_host()
+        monkeypatch.setenv("KS_DEBUG_INDEX_LSD", "1")
+        b = ctx.search(ctx.index_build(T), Q).to_host()
+        monkeypatch.delenv("KS_DEBUG_INDEX_LSD")
+        assert len(want[0]) > 0
+        for x, y, w in zip(a, b, want):
+            assert np.array_equal(x, w) and np.array_equal(y, w)
+
+
 def test_index_build_falls_back_on_duplicated_targets(ctx, monkeypatch):
     """4000 copies of one protein: every hash of the index occurs 4000 times, so the sort buckets overflow their fixed
     capacity and the build must take the LSD path — same hits as forcing that path, and every query finds every copy."""
