@@ -308,10 +308,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *keys, u32 
     u64 base;
     u32 nvalid;
     rs_tile_geom(blockIdx.x, n, seg_len, seg_cap, tiles_per_seg, base, nvalid);
+    u64 key[RS_IPT]; // (requested together: a load inside the guarded loop is waited for in every turn)
 #pragma unroll
     for (int i = 0; i < RS_IPT; i++) {
         const u32 li = (u32)i * RS_THREADS + threadIdx.x;
-        if (li < nvalid) atomicAdd(&bins[ks_rs_digit(keys[base + li], shift, pfxK)], 1u);
+        key[i] = li < nvalid ? keys[base + li] : 0ULL;
+    }
+#pragma unroll
+    for (int i = 0; i < RS_IPT; i++) {
+        const u32 li = (u32)i * RS_THREADS + threadIdx.x;
+        if (li < nvalid) atomicAdd(&bins[ks_rs_digit(key[i], shift, pfxK)], 1u);
     }
     __syncthreads();
     if (threadIdx.x < 256) hist[(u64)threadIdx.x * nblocks + blockIdx.x] = bins[threadIdx.x];

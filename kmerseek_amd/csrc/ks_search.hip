@@ -1044,12 +1044,20 @@ __global__ __launch_bounds__(256) void k_pairs_compact(const u64 *src_k, const u
     const u64 n = tab.prefix[s + 1] - tab.prefix[s], i0 = (u64)blockIdx.x * 2048;
     const u64 *sk = src_k + (u64)s * seg_cap;
     u64 *dk = dst_k + tab.prefix[s];
+    u64 kk[8]; // (requested together, then stored)
+    u32 vv[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const u64 i = i0 + (u64)j * 256 + threadIdx.x;
+        kk[j] = i < n ? sk[i] : 0ULL;
+        vv[j] = (src_v && i < n) ? src_v[(u64)s * seg_cap + i] : 0u;
+    }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const u64 i = i0 + (u64)j * 256 + threadIdx.x;
         if (i < n) {
-            dk[i] = sk[i];
-            if (src_v) dst_v[tab.prefix[s] + i] = src_v[(u64)s * seg_cap + i];
+            dk[i] = kk[j];
+            if (src_v) dst_v[tab.prefix[s] + i] = vv[j];
         }
     }
 }
@@ -1157,12 +1165,20 @@ __global__ __launch_bounds__(PF_THREADS) void k_pair_rows_fused(const u64 *keys,
         const u64 i = b0 + (u64)r * PF_THREADS + tid_;
         key[r] = i < n ? keys[i] : 0;
     }
+    // The previous record: the lane below's (two DPP moves, no LDS crossbar), except for lane 0, whose predecessor sits in the
+    // previous wave / round / tile: lane r of the wave loads it for round r — one register pair and ONE memory latency for all
+    // rounds (a load inside the loop was waited for in every round: eight dependent latencies per tile).
+    u64 pp = 0;
+    {
+        const u64 iw = b0 + (u64)lane * PF_THREADS + (tid_ & ~63u); // lane r: where this wave's round r starts
+        if (lane < PF_IPT && iw > 0 && iw < n) pp = keys[iw - 1];
+    }
 #pragma unroll
     for (int r = 0; r < PF_IPT; r++) {
         const u64 i = b0 + (u64)r * PF_THREADS + tid_;
-        // the previous record: the neighbouring lane's, except for lane 0 (previous wave / round / tile: one extra load)
-        u64 prev = __shfl_up(key[r], 1, 64);
-        if (lane == 0 && i > 0 && i < n) prev = keys[i - 1];
+        const u64 below = ((u64)ks_lane_below((u32)(key[r] >> 32)) << 32) | ks_lane_below((u32)key[r]);
+        const u64 first = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(pp >> 32), r) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)pp, r);
+        const u64 prev = lane ? below : first;
         const bool head = i < n && (i == 0 || (prev >> abits) != (key[r] >> abits));
         headbits |= head ? (1u << r) : 0u;
         const u64 m = __ballot(head);
