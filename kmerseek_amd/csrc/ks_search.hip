@@ -1244,13 +1244,31 @@ __global__ __launch_bounds__(PF_THREADS) void k_pair_rows_fused(const u64 *keys,
             qid[row] = (u32)(ids >> tbits);
             tid[row] = (u32)(ids & ((1ULL << tbits) - 1ULL));
         }
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { // inclusive segmented scan (segments = equal row, rows ascend)
-            const u64 ow = __shfl_up(w, d, 64);
-            const u32 oc = __shfl_up(c, d, 64), orow = __shfl_up(row, d, 64);
-            if (lane >= (u32)d && orow == row) { w += ow; c += oc; }
+        // Inclusive segmented scan (segments = equal row; rows ascend, so a lane whose source has my row continues my segment) with DPP
+        // moves only: four row_shr steps inside the rows of 16, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 — the
+        // __shfl_up form was 25 ds_bpermute per round, 213 per thread: the LDS crossbar was this kernel (19 M wave-level permutes
+        // for the 49 M records of a 200k all-vs-all).  A lane without a source reads `rowx`, which is not its row: it adds nothing.
+        {
+            const u32 rowx = row ^ 1u;
+            u32 wl = (u32)w, wh = (u32)(w >> 32);
+#define PF_SEG_STEP(CTRL, RMASK) do { \
+                const u32 orow = (u32)__builtin_amdgcn_update_dpp((int)rowx, (int)row, CTRL, RMASK, 0xf, false); \
+                const u32 oc = (u32)__builtin_amdgcn_update_dpp(0, (int)c, CTRL, RMASK, 0xf, false); \
+                const u32 ol = (u32)__builtin_amdgcn_update_dpp(0, (int)wl, CTRL, RMASK, 0xf, false); \
+                const u32 oh = (u32)__builtin_amdgcn_update_dpp(0, (int)wh, CTRL, RMASK, 0xf, false); \
+                const bool same = orow == row; \
+                const u64 nw_ = (((u64)wh << 32) | wl) + (same ? (((u64)oh << 32) | ol) : 0ULL); \
+                c += same ? oc : 0u; wl = (u32)nw_; wh = (u32)(nw_ >> 32); } while (0)
+            PF_SEG_STEP(0x111, 0xf); // row_shr:1
+            PF_SEG_STEP(0x112, 0xf); // row_shr:2
+            PF_SEG_STEP(0x114, 0xf); // row_shr:4
+            PF_SEG_STEP(0x118, 0xf); // row_shr:8
+            PF_SEG_STEP(0x142, 0xa); // row_bcast:15 -> rows 1 and 3
+            PF_SEG_STEP(0x143, 0xc); // row_bcast:31 -> rows 2 and 3
+#undef PF_SEG_STEP
+            w = ((u64)wh << 32) | wl;
         }
-        const u32 nrow = __shfl_down(row, 1, 64);
+        const u32 nrow = (u32)__builtin_amdgcn_update_dpp((int)(row ^ 1u), (int)row, 0x130, 0xf, 0xf, false); // wave_shl:1 (lane 63: not its row)
         // (Measured dead end: STORING the rows whose records all sit inside one wave — most rows of an all-vs-all search are one or
         // two records — instead of adding them: 0.45 -> 0.83 ms at 200k x 200k hp.  Scattered 4- / 8-byte stores of a wave cost
         // more than the same no-return atomics, which the L2 merges line by line.  Handing the head lanes' ids to lanes 0 .. heads-1
