@@ -428,7 +428,8 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_radix_scatter(const u64
 // V16 = 2: 16 bits in, 8 bits out (9-byte postings; join prefixes of 16 bits only): the bucket implies the key's top byte too —
 // it is this pass's digit —, so the low byte of the value moves there and its high byte is the 8-bit column that leaves.
 template <int V16>
-__global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout,
+// (two workgroups of 8 waves per CU by the 70 KB of LDS: 4 waves per SIMD, i.e. a budget of 128 registers)
+__global__ __launch_bounds__(RS_THREADS, 4) void k_bucket_scatter(const u64 *kin, const u32 *vin, u64 *kout, u32 *vout,
                                                                         int shift, const u32 *seg_len, u64 seg_cap,
                                                                         u32 tiles_per_seg, u32 *bcur, u32 bcap,
                                                                         unsigned long long *status, u32 pfxK, u32 n_hi, u32 sub_shift) {
@@ -462,13 +463,27 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
         val[r] = valid ? (V16 ? (u32)((const u16 *)vin)[tile_base + li] : vin[tile_base + li]) : 0u;
     }
     __syncthreads();
+    // A full tile — all but the last of a sub-region — ranks its records without a guard: sixteen LDS atomics in flight, one wait.
+    // (Behind `if (li < nvalid)` every atomic sat in a branch of its own and was waited for in turn: sixteen LDS round trips in a
+    // row per thread, with four waves per SIMD to hide them.)
+    const bool full = nvalid == RS_TILE; // (uniform)
+    if (full) {
+        u32 dg[RS_IPT];
 #pragma unroll
-    for (int r = 0; r < RS_IPT; r++) {
-        const u32 li = (u32)r * RS_THREADS + tid;
-        rank[r] = 0xffffffffu;
-        if (li < nvalid) {
-            const u32 d = (ks_join_prefix(key[r], pfxK) >> shift) & (n_hi - 1u);
-            rank[r] = (d << 16) | atomicAdd(&cnt[d], 1u);
+        for (int r = 0; r < RS_IPT; r++) dg[r] = (ks_join_prefix(key[r], pfxK) >> shift) & (n_hi - 1u);
+#pragma unroll
+        for (int r = 0; r < RS_IPT; r++) rank[r] = atomicAdd(&cnt[dg[r]], 1u);
+#pragma unroll
+        for (int r = 0; r < RS_IPT; r++) rank[r] |= dg[r] << 16;
+    } else {
+#pragma unroll
+        for (int r = 0; r < RS_IPT; r++) {
+            const u32 li = (u32)r * RS_THREADS + tid;
+            rank[r] = 0xffffffffu;
+            if (li < nvalid) {
+                const u32 d = (ks_join_prefix(key[r], pfxK) >> shift) & (n_hi - 1u);
+                rank[r] = (d << 16) | atomicAdd(&cnt[d], 1u);
+            }
         }
     }
     __syncthreads();
@@ -487,9 +502,14 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
         }
     }
     __syncthreads();
+    if (full) {
 #pragma unroll
-    for (int r = 0; r < RS_IPT; r++)
-        if (rank[r] != 0xffffffffu) rank[r] = dstart[rank[r] >> 16] + (rank[r] & 0xffffu);
+        for (int r = 0; r < RS_IPT; r++) rank[r] = dstart[rank[r] >> 16] + (rank[r] & 0xffffu);
+    } else {
+#pragma unroll
+        for (int r = 0; r < RS_IPT; r++)
+            if (rank[r] != 0xffffffffu) rank[r] = dstart[rank[r] >> 16] + (rank[r] & 0xffffu);
+    }
     u32 vo[V16 == 2 ? RS_IPT : 1]; // V16 = 2: the values in output order, before the keys go through the same buffer
     if (V16 == 2) {
         u32 *vstage0 = (u32 *)stage;
@@ -505,23 +525,32 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
     for (int r = 0; r < RS_IPT; r++)
         if (rank[r] != 0xffffffffu) stage[rank[r]] = key[r];
     __syncthreads();
-    u64 gdst[RS_IPT]; // global destination of local slot i*RS_THREADS + tid
+    // The staged records and their digits' table entries are READ together (48 LDS reads in flight), then stored: one read, two
+    // dependent table reads and the stores per record in turn were 32 LDS latencies in a row per thread.
+    u32 dd[RS_IPT], sl[RS_IPT]; // digit and slot inside the bucket of local slot i * RS_THREADS + tid (sl = ~0: nothing to store)
+    {
+        u64 ks_[RS_IPT];
 #pragma unroll
-    for (int i = 0; i < RS_IPT; i++) {
-        const u32 p = (u32)i * RS_THREADS + tid;
-        gdst[i] = ~0ULL;
-        if (p < nvalid) {
-            const u64 k = stage[p];
-            const u32 d = (ks_join_prefix(k, pfxK) >> shift) & (n_hi - 1u);
-            const u32 slot = gbase[d] + (p - dstart[d]);
-            if (slot < bcap) {
-                gdst[i] = (u64)KS_BSLOT(d, region, n_hi) * bcap + slot;
+        for (int i = 0; i < RS_IPT; i++) ks_[i] = stage[(u32)i * RS_THREADS + tid]; // (slots behind nvalid: stale, masked below)
+#pragma unroll
+        for (int i = 0; i < RS_IPT; i++) {
+            const u32 p = (u32)i * RS_THREADS + tid;
+            dd[i] = (ks_join_prefix(ks_[i], pfxK) >> shift) & (n_hi - 1u);
+            sl[i] = gbase[dd[i]] + (p - dstart[dd[i]]);
+        }
+#pragma unroll
+        for (int i = 0; i < RS_IPT; i++) {
+            const u32 p = (u32)i * RS_THREADS + tid;
+            if (!(p < nvalid && sl[i] < bcap)) sl[i] = 0xffffffffu;
+            if (sl[i] != 0xffffffffu) {
+                const u64 k = ks_[i];
+                const u64 g = (u64)KS_BSLOT(dd[i], region, n_hi) * bcap + sl[i];
                 if (V16 == 2) {
                     const u32 v = vo[V16 == 2 ? i : 0];
-                    kout[gdst[i]] = (k & ~(0xffULL << 56)) | ((u64)(v & 0xffu) << 56);
-                    ((u8 *)vout)[gdst[i]] = (u8)(v >> 8);
+                    kout[g] = (k & ~(0xffULL << 56)) | ((u64)(v & 0xffu) << 56);
+                    ((u8 *)vout)[g] = (u8)(v >> 8);
                 } else {
-                    kout[gdst[i]] = k;
+                    kout[g] = k;
                 }
             }
         }
@@ -529,15 +558,21 @@ __global__ __launch_bounds__(RS_THREADS, RS_MINW) void k_bucket_scatter(const u6
     if (V16 == 2) return;
     __syncthreads();
     u32 *vstage = (u32 *)stage;
+    if (full) {
 #pragma unroll
-    for (int r = 0; r < RS_IPT; r++)
-        if (rank[r] != 0xffffffffu) vstage[rank[r]] = val[r];
+        for (int r = 0; r < RS_IPT; r++) vstage[rank[r]] = val[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < RS_IPT; r++)
+            if (rank[r] != 0xffffffffu) vstage[rank[r]] = val[r];
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < RS_IPT; i++)
-        if (gdst[i] != ~0ULL) {
-            if (V16) ((u16 *)vout)[gdst[i]] = (u16)vstage[(u32)i * RS_THREADS + tid];
-            else vout[gdst[i]] = vstage[(u32)i * RS_THREADS + tid];
+        if (sl[i] != 0xffffffffu) {
+            const u64 g = (u64)KS_BSLOT(dd[i], region, n_hi) * bcap + sl[i];
+            if (V16) ((u16 *)vout)[g] = (u16)vstage[(u32)i * RS_THREADS + tid];
+            else vout[g] = vstage[(u32)i * RS_THREADS + tid];
         }
 }
 
