@@ -278,24 +278,12 @@ KS_DEV u32 sk_place_window(const sk_args &A, u32 p, u64 h, sk_seq &q, const sk_b
     return bo;
 }
 
-// The same for k >= SK_E, branch-free in the sequence: a sequence's last k - 1 positions start no window, so the SK_E
-// consecutive positions of a thread hold windows of at most ONE sequence — the first whose last window lies at or beyond the
-// thread's first position (found once per thread: the binary search of phase 2 with key q0 + k - 1) — and a position p
-// starts a real window of it iff (p - ls) < nw, unsigned.  No per-window walk over the boundaries, no per-window sequence
-// code (round 3: a compare + branch + three range tests per window, 25 vector + 14 scalar instructions of bookkeeping per
-// window against 66 of hashing; profiles/r03_sq_counters.md).  `thr`: the keep-below-threshold test (scaled > 1 only).
-KS_DEV u32 sk_place_window_run(u32 p, u64 h, u32 ls, u32 nw, u32 mul, u32 s24, bool thr, u64 max_hash, u32 *cnt) {
-    bool keep = (p - ls) < nw && h != 0;
-    if (thr) keep = keep && h <= max_hash;
-    u32 bo = 0xffffffffu;
-    if (keep) {
-        const u32 b = ls + __umulhi((u32)(h >> 32), mul);
-        const u32 sh = b << 4; // (only bits [4:0] of a shift amount / bit-field offset count: (b & 1) * 16)
-        const u32 o = __builtin_amdgcn_ubfe(atomicAdd(&cnt[b >> 1], 1u << (sh & 31u)), sh, 16u); // two 16-bit counters per word
-        bo = s24 | (b << 12) | o; // b, o < 4096
-    }
-    return bo;
-}
+// k >= SK_E ("one run"): a sequence's last k - 1 positions start no window, so the SK_E consecutive positions of a thread hold
+// windows of at most ONE sequence — the first whose last window lies at or beyond the thread's first position (found once per
+// thread: the binary search of phase 2 with key q0 + k - 1) — and a position p starts a real window of it iff (p - ls) < nw,
+// unsigned.  No per-window walk over the boundaries, no per-window sequence code (round 3: a compare + branch + three range
+// tests per window, 25 vector + 14 scalar instructions of bookkeeping per window against 66 of hashing;
+// profiles/r03_sq_counters.md).  The placement itself is written out in phase 2 (all eight atomics in flight together).
 
 // ---------------------------------------------------------------------------------------------
 // Packed tiles (plain variant, scaled = 1): instead of cutting the batch at fixed residue strides — where a stride of 3312
@@ -392,7 +380,7 @@ KS_DEV void sk_cmp_half(const sk_args &A, const sk_bounds &B, sk_seq &q, const u
             h[6] = sk_hash_window<H + 6, KC>(wl, A.k, A.seed);
             h[7] = sk_hash_window<H + 7, KC>(wl, A.k, A.seed);
         }
-        if ((KC ? (u32)KC : A.k) >= SK_E) { // (uniform) one sequence per thread: sk_place_window_run
+        if ((KC ? (u32)KC : A.k) >= SK_E) { // (uniform) one sequence per thread (see sk_place_window)
             const u32 srel = q.s - s_first;
 #pragma unroll
             for (int i = 0; i < NW; i++)
@@ -457,7 +445,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     __shared__ u32 lds_pad[SK_LDS_PAD / 4];
     if (threadIdx.x == 0 && A.n_res == 0xfffffffffffffffULL) lds_pad[A.k] = 1;
 #endif
-    __shared__ u32 bins[256];  // postings: count per digit, then the digit's start inside the tile
+    __shared__ u32 bins[256 + 1];  // postings: count per digit, then the digit's start inside the tile (+ a word that takes the adds of 0)
     __shared__ unsigned long long gaddr[256]; // postings: slot of the tile's first element of each digit, minus the digit's start inside the tile
 
     const u32 tid = threadIdx.x;
@@ -487,6 +475,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     // guarantees the order by construction.
     if (MODE == 0 && tid == 0) ticket_v = A.use_ticket ? atomicAdd(&A.ticket[0], 1u) : tile_in;
     if (tid < 256) { lut_s[tid] = A.lut[tid]; bins[tid] = 0; }
+    if (tid == 256) bins[256] = 0;
     for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
     if (tid < SK_NFLAG) flagbits[tid] = 0;
     __shared__ u32 n_list_s; // CMP: kept windows appended to the list so far
@@ -569,7 +558,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     const u32 q0 = tid * SK_E;
     sk_seq q;
     const u32 kk = KC ? (u32)KC : A.k;
-    const bool onerun = kk >= SK_E; // (uniform; compile-time for the folded k-mer sizes) see sk_place_window_run
+    const bool onerun = kk >= SK_E; // (uniform; compile-time for the folded k-mer sizes) see the note behind sk_place_window
     {
         // first sequence of the tile whose end lies beyond q0 — whose LAST WINDOW lies at or beyond q0 when k >= SK_E
         const u32 key = onerun ? q0 + kk - 1u : q0;
@@ -691,8 +680,25 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             const u32 srel = q.s - B.s_first;
             const u32 s24 = (srel < 254u ? srel : 254u) << 24;
             const bool thr = A.max_hash != ~0ULL; // (uniform)
+            // The eight bucket counters' atomics leave together and are awaited once: a window that is not kept adds 0 to a spare
+            // counter word instead of sitting out in a branch of its own (which put a wait behind every atomic: eight LDS round
+            // trips in a row per thread, sixteen with the posting ranks below).
+            u32 bb[SK_E], rt[SK_E];
+            u32 kpm = 0;
 #pragma unroll
-            for (int i = 0; i < SK_E; i++) bo[i] = sk_place_window_run(q0 + i, h[i], q.ls, q.nw, q.mul, s24, thr, A.max_hash, cnt);
+            for (int i = 0; i < SK_E; i++) {
+                bool keep = (q0 + (u32)i - q.ls) < q.nw && h[i] != 0;
+                if (thr) keep = keep && h[i] <= A.max_hash;
+                kpm |= keep ? (1u << i) : 0u;
+                const u32 b = q.ls + __umulhi((u32)(h[i] >> 32), q.mul);
+                bb[i] = keep ? b : (u32)SK_TILE + 2u; // (counter word SK_TILE / 2 + 1: never a bucket's)
+            }
+#pragma unroll
+            for (int i = 0; i < SK_E; i++)
+                rt[i] = atomicAdd(&cnt[bb[i] >> 1], ((kpm >> i) & 1u) << ((bb[i] << 4) & 31u)); // two 16-bit counters per word
+#pragma unroll
+            for (int i = 0; i < SK_E; i++)
+                bo[i] = ((kpm >> i) & 1u) ? (s24 | (bb[i] << 12) | __builtin_amdgcn_ubfe(rt[i], bb[i] << 4, 16u)) : 0xffffffffu;
         } else {
 #pragma unroll
             for (int i = 0; i < SK_E; i++) bo[i] = sk_place_window(A, q0 + i, h[i], q, B, s_end, cnt);
@@ -702,10 +708,14 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         // postings straight from these window-order registers: no sequence lookup, no counting phase of its own.
         if (early) {
             if (A.part_kshift) { // (uniform; decided once, not per window: the digit is a shift at scaled = 1)
+                u32 rr[SK_E];
 #pragma unroll
-                for (int i = 0; i < SK_E; i++)
-                    if (bo[i] != 0xffffffffu)
-                        rkp[i >> 1] |= atomicAdd(&bins[((u32)(h[i] >> 32) >> A.part_kshift) & A.part_mask], 1u) << ((i & 1) * 16); // < SK_TILE
+                for (int i = 0; i < SK_E; i++) {
+                    const bool kept = bo[i] != 0xffffffffu;
+                    rr[i] = atomicAdd(&bins[kept ? (((u32)(h[i] >> 32) >> A.part_kshift) & A.part_mask) : 256u], kept ? 1u : 0u); // < SK_TILE
+                }
+#pragma unroll
+                for (int i = 0; i < SK_E; i++) rkp[i >> 1] |= (bo[i] != 0xffffffffu ? rr[i] : 0u) << ((i & 1) * 16);
             } else {
 #pragma unroll
                 for (int i = 0; i < SK_E; i++)
