@@ -820,9 +820,14 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
 
     SK_STAMP_AT(3);
     // ---- phase 4: scatter kept hashes into bucket order; sorted position at which every sequence's run starts
+    {
+        u32 st8[SK_E]; // (the eight bucket starts are read together — the bucket field of "no window" is a bucket like any other —, then stored behind)
 #pragma unroll
-    for (int i = 0; i < SK_E; i++)
-        if (bo[i] != 0xffffffffu) tmp[bstart(SK_BO_B(bo[i])) + SK_BO_O(bo[i])] = h[i];
+        for (int i = 0; i < SK_E; i++) st8[i] = bstart(SK_BO_B(bo[i]));
+#pragma unroll
+        for (int i = 0; i < SK_E; i++)
+            if (bo[i] != 0xffffffffu) tmp[st8[i] + SK_BO_O(bo[i])] = h[i];
+    }
     if (B.in_lds) {
         for (u32 i = tid; i <= ns; i += SK_THREADS) // (first bucket of a sequence: its local start, or the compacted base of the bucket table)
             dseq[i] = (u16)(i == ns ? n_kept : bstart(CMP ? ((const uint2 *)res_w)[i].x : loff[i]));
@@ -1116,10 +1121,13 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     // sequence codes through the counter words, then one run per digit.
     auto post_emit = [&]() {
         u16 *qrel = (u16 *)cnt; // sequence (relative) of the element staged at tmp[pos]
+        u32 ds8[SK_E]; // (the eight digit starts are read together; a slot without a representative reads some digit's start and drops it)
+#pragma unroll
+        for (int i = 0; i < SK_E; i++) ds8[i] = bins[sk_digit(h[i], A.part_K, A.part_kshift, A.part_mask)];
 #pragma unroll
         for (int i = 0; i < SK_E; i++)
             if (rep & (1u << i)) {
-                const u32 pos = bins[sk_digit(h[i], A.part_K, A.part_kshift, A.part_mask)] + rk[i];
+                const u32 pos = ds8[i] + rk[i];
                 tmp[pos] = h[i];
                 qrel[pos] = (u16)((srl[i >> 2] >> (8 * (i & 3))) & 0xffu);
             }
