@@ -474,7 +474,11 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     // into a flag, and the host then repeats the launch with ids drawn from an atomic ticket (use_ticket), which
     // guarantees the order by construction.
     if (MODE == 0 && tid == 0) ticket_v = A.use_ticket ? atomicAdd(&A.ticket[0], 1u) : tile_in;
-    if (tid < 256) { lut_s[tid] = A.lut[tid]; bins[tid] = 0; }
+    // The encode table's byte is REQUESTED here and stored behind the plan loads below (stored at once, the workgroup sat out one
+    // memory latency before it asked for anything else); moltype protein does not use the table at all.
+    u32 lut_v = 0;
+    if (!A.upper_only && tid < 256) lut_v = A.lut[tid];
+    if (tid < 256) bins[tid] = 0;
     if (tid == 256) bins[256] = 0;
     for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
     if (tid < SK_NFLAG) flagbits[tid] = 0;
@@ -516,12 +520,18 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     };
     uint4 rv = make_uint4(0, 0, 0, 0);
     const bool packed = MODE == 0 && !CMP && A.R == 0; // (uniform) packed tiles: the window starts where the plan says
+    // The plan entries of the tile — where its residues start, its first and last sequence — are three independent loads: all
+    // three are requested before the first is used (in source order "g0, residues(g0), sequences" the residues' request waited
+    // for g0 and the sequence range was only asked for behind it: four dependent memory latencies from launch to the first
+    // residue in LDS, now two: {table byte, g0, sequence range} -> {residues, sequence boundaries}).
+    tile = (u32)__builtin_amdgcn_readfirstlane((int)tile); // (uniform: scalar loads)
     u64 g0p = 0;
     if (packed) g0p = A.tile_g0[tile];
-    if (MODE == 0 && tid < NCH) rv = load_chunk((packed ? g0p : (u64)tile * A.R) + (u64)tid * 16); // R is a multiple of 16
     u32 s_first, s_end;
     if (MODE == 1) { s_first = A.seq_list[tile]; s_end = s_first + 1; }
     else { s_first = A.seq_list[tile]; s_end = A.seq_list[tile + 1]; }
+    if (!A.upper_only && tid < 256) lut_s[tid] = (u8)lut_v;
+    if (MODE == 0 && tid < NCH) rv = load_chunk((packed ? g0p : (u64)tile * A.R) + (u64)tid * 16); // R is a multiple of 16
     if (s_first >= s_end) {
         if (MODE == 0 && tid == 0)
             __hip_atomic_store(&A.tile_status[tile], SK_FLAG_AGG | 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
