@@ -869,7 +869,7 @@ __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8
     const u64 *dir_t, u64 *pair_keys, u32 *pair_vals, u64 cap, unsigned long long *cursors, u32 seg_mask, int tbits, int abits,
     int fp_shift) {
     __shared__ u64 qh[JS_QCAP];                       // query hashes, in slot order
-    __shared__ u32 qf[JS_QCAP];                       // their fingerprints
+    __shared__ u32 qf[JS_QCAP + 2];                   // their fingerprints (+ 2: the probes read two entries of a slot whatever it holds)
     __shared__ unsigned short qi[JS_QCAP];            // their place in the bucket's posting list
     __shared__ u32 qdir[JS_DIR + 1];                  // counts, then first table entry of every slot
     __shared__ u32 wlist[JS_THREADS / 64][JS_WLIST];  // per-wave candidate list: index posting (this pass) << 10 | table entry
@@ -955,17 +955,35 @@ __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8
                     const u32 i = i0 + (u32)(JS_G + j) * JS_THREADS + tid;
                     fb[j] = (g + 1 < (u32)(JS_IPT / JS_G) && i < n) ? fpc[i] : 0;
                 }
+                // The group's JS_G slots are looked up together: their directory words (2 x JS_G LDS reads in flight), then the first
+                // two table entries of every slot (a slot holds 0.55 queries on average), then the compares — the per-fingerprint
+                // form (directory words, wait, entry, wait, entry ...) was two to three dependent LDS latencies per fingerprint,
+                // twenty fingerprints per thread and pass in a row.
+                u32 d0[JS_G], d1[JS_G], e0[JS_G], e1[JS_G];
+#pragma unroll
+                for (int j = 0; j < JS_G; j++) {
+                    const u32 sl = js_slot(fa[j], dirM); // (a lane behind n holds fingerprint 0: slot 0, dropped below)
+                    d0[j] = qdir[sl]; d1[j] = qdir[sl + 1];
+                }
+#pragma unroll
+                for (int j = 0; j < JS_G; j++) { e0[j] = qf[d0[j]]; e1[j] = qf[d0[j] + 1u]; }
 #pragma unroll
                 for (int j = 0; j < JS_G; j++) {
                     const u32 i = i0 + (u32)j * JS_THREADS + tid;
-                    if (i < n) {
-                        const u32 sl = js_slot(fa[j], dirM);
-                        for (u32 r = qdir[sl]; r < qdir[sl + 1]; r++)
-                            if (qf[r] == fa[j]) {
-                                const u32 p = atomicAdd(&wcount[wave], 1u);
-                                if (p < (u32)JS_WLIST) wlist[wave][p] = (i << 10) | r;
-                            }
+                    const u32 cnt = i < n ? d1[j] - d0[j] : 0u;
+                    if (cnt >= 1u && e0[j] == fa[j]) {
+                        const u32 p = atomicAdd(&wcount[wave], 1u);
+                        if (p < (u32)JS_WLIST) wlist[wave][p] = (i << 10) | d0[j];
                     }
+                    if (cnt >= 2u && e1[j] == fa[j]) {
+                        const u32 p = atomicAdd(&wcount[wave], 1u);
+                        if (p < (u32)JS_WLIST) wlist[wave][p] = (i << 10) | (d0[j] + 1u);
+                    }
+                    for (u32 r = d0[j] + 2u; r < d0[j] + cnt; r++) // (rare: a crowded slot)
+                        if (qf[r] == fa[j]) {
+                            const u32 p = atomicAdd(&wcount[wave], 1u);
+                            if (p < (u32)JS_WLIST) wlist[wave][p] = (i << 10) | r;
+                        }
                 }
 #pragma unroll
                 for (int j = 0; j < JS_G; j++) fa[j] = fb[j];
