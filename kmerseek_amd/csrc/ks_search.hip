@@ -854,8 +854,12 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
 #define JS_THREADS 256
 #define JS_QCAP 1024  // query postings per table build (more: the bucket is joined in slices)
 #define JS_QE (JS_QCAP / JS_THREADS)
-#define JS_IPT 20     // index fingerprints per thread and pass
-#define JS_G 4        // ... of which this many are in flight per group
+#ifndef JS_IPT
+#define JS_IPT 18     // index fingerprints per thread and pass (4,608: a bucket of ~4.5k in one pass)
+#endif
+#ifndef JS_G
+#define JS_G 6        // ... of which this many are in flight per group (with the group's slots looked up together: 4 -> 0.512 ms,
+#endif                //     5 -> 0.495, 6 -> 0.471, 7 -> 0.473 for the 125k-query shard; 8 spills: 0.56)
 #define JS_DIR 1024   // directory slots over the table
 #define JS_WLIST 128  // candidates a wave lists per pass
 KS_DEV u32 js_slot(u32 f, u32 mul) { // slot of a fingerprint: the bucket's JN_DIR slot mapping, coarsened
