@@ -742,22 +742,32 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
                     }
                 }
                 __builtin_amdgcn_wave_barrier(); // same wave: LDS operations execute in order
+                // Everything a candidate needs is REQUESTED before anything is compared: the index posting as one 16-byte load, the
+                // query's id (its key word and its value byte), for both rounds of the list.  (Written as "load the posting, compare,
+                // then take tid / abundance / id" the compiler loaded the posting's key alone, waited, and fetched the rest inside the
+                // branch: two dependent memory latencies per round — and nearly every candidate IS a match.)
+                uint4 praw[JN_WLIST / 64];
+                u32 qcand[JN_WLIST / 64];
+                u64 hcand[JN_WLIST / 64];
 #pragma unroll
                 for (int it = 0; it < JN_WLIST / 64; it++) {
-                    rk[it] = 0; rv[it] = 0;
                     const u32 k = (u32)it * 64u + lane;
-                    if (k < wtotal) {
-                        const u32 en = wlist[wave][k];
-                        const ks_post pt = postc[en >> 13];
-                        const u32 q = QF.qid(qkr, qir, en & 0x1fffu);
-                        if (QF.same(pt.key, wlist_h[wave][k])) { // confirmed
-                            const u64 ids = ((u64)q << tbits) | pt.tid; // ids packed tight: fewer sort passes
-                            rk[it] = pair_vals ? ids : ((ids << abits) | pt.abund); // packed: one 8-byte record per match
-                            rv[it] = pt.abund;
-                            okm |= 1u << it;
-                            conf++;
-                        }
-                    }
+                    const u32 en = k < wtotal ? wlist[wave][k] : 0u; // (a lane without a candidate reads posting 0 and query 0 of the bucket)
+                    praw[it] = *(const uint4 *)&postc[en >> 13];
+                    qcand[it] = QF.qid(qkr, qir, en & 0x1fffu);
+                    hcand[it] = wlist_h[wave][k < wtotal ? k : 0u];
+                }
+#pragma unroll
+                for (int it = 0; it < JN_WLIST / 64; it++) {
+                    const u32 k = (u32)it * 64u + lane;
+                    const u64 pkey = ((u64)praw[it].y << 32) | praw[it].x;
+                    const u32 ptid = praw[it].z, pab = praw[it].w;
+                    const bool ok = k < wtotal && QF.same(pkey, hcand[it]); // confirmed
+                    const u64 ids = ((u64)qcand[it] << tbits) | ptid; // ids packed tight: fewer sort passes
+                    rk[it] = ok ? (pair_vals ? ids : ((ids << abits) | pab)) : 0ULL; // packed: one 8-byte record per match
+                    rv[it] = ok ? pab : 0u;
+                    okm |= ok ? (1u << it) : 0u;
+                    conf += ok ? 1u : 0u;
                 }
                 __builtin_amdgcn_wave_barrier();
             } else { // a hash shared by many targets: confirm whole runs, emit straight from the registers
@@ -999,22 +1009,28 @@ __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8
                 // lane k confirms and emits candidate k
                 u64 rk[JS_WLIST / 64];
                 u32 rv[JS_WLIST / 64], okm = 0, conf = 0;
+                // (posting — one 16-byte load — and query id requested for both rounds before anything is compared: see k_join_buckets)
+                uint4 praw[JS_WLIST / 64];
+                u32 qcand[JS_WLIST / 64], rcand[JS_WLIST / 64];
 #pragma unroll
                 for (int it = 0; it < JS_WLIST / 64; it++) {
-                    rk[it] = 0; rv[it] = 0;
                     const u32 k = (u32)it * 64u + lane;
-                    if (k < wtotal) {
-                        const u32 en = wlist[wave][k], r = en & 1023u;
-                        const ks_post pt = postc[en >> 10];
-                        const u32 q = QF.qid(qkr, qir, qi[r]);
-                        if (pt.key == qh[r]) {
-                            const u64 ids = ((u64)q << tbits) | pt.tid;
-                            rk[it] = pair_vals ? ids : ((ids << abits) | pt.abund);
-                            rv[it] = pt.abund;
-                            okm |= 1u << it;
-                            conf++;
-                        }
-                    }
+                    const u32 en = k < wtotal ? wlist[wave][k] : 0u; // (a lane without a candidate reads posting 0 and table entry 0)
+                    rcand[it] = en & 1023u;
+                    praw[it] = *(const uint4 *)&postc[en >> 10];
+                    qcand[it] = QF.qid(qkr, qir, qi[rcand[it]]);
+                }
+#pragma unroll
+                for (int it = 0; it < JS_WLIST / 64; it++) {
+                    const u32 k = (u32)it * 64u + lane;
+                    const u64 pkey = ((u64)praw[it].y << 32) | praw[it].x;
+                    const u32 ptid = praw[it].z, pab = praw[it].w;
+                    const bool ok = k < wtotal && pkey == qh[rcand[it]];
+                    const u64 ids = ((u64)qcand[it] << tbits) | ptid;
+                    rk[it] = ok ? (pair_vals ? ids : ((ids << abits) | pab)) : 0ULL;
+                    rv[it] = ok ? pab : 0u;
+                    okm |= ok ? (1u << it) : 0u;
+                    conf += ok ? 1u : 0u;
                 }
                 const u32 cincl = ks_wave_incl_scan(conf);
                 const u32 total = __shfl(cincl, 63, 64);
