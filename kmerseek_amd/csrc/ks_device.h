@@ -133,6 +133,24 @@ KS_DEV u32 ks_wave_incl_scan(u32 v) {
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
     return v;
 }
+// Sum of a 64-bit value over the 64 lanes of a wave (uniform result), DPP moves only: the look-backs' reduce used to be
+// `v += __shfl_xor(v, d)` — twelve ds_bpermute in a row on the critical path of every tile.
+KS_DEV u64 ks_wave_sum64(u64 v) {
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+#define KS_SUM64_STEP(CTRL, RMASK, BC) do { \
+        const u32 ol_ = (u32)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, RMASK, 0xf, BC); \
+        const u32 oh_ = (u32)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, RMASK, 0xf, BC); \
+        const u64 s_ = (((u64)hi << 32) | lo) + (((u64)oh_ << 32) | ol_); \
+        lo = (u32)s_; hi = (u32)(s_ >> 32); } while (0)
+    KS_SUM64_STEP(0x111, 0xf, true);  // row_shr:1
+    KS_SUM64_STEP(0x112, 0xf, true);  // row_shr:2
+    KS_SUM64_STEP(0x114, 0xf, true);  // row_shr:4
+    KS_SUM64_STEP(0x118, 0xf, true);  // row_shr:8
+    KS_SUM64_STEP(0x142, 0xa, false); // row_bcast:15 into rows 1 and 3
+    KS_SUM64_STEP(0x143, 0xc, false); // row_bcast:31 into rows 2 and 3
+#undef KS_SUM64_STEP
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (u32)__builtin_amdgcn_readlane((int)lo, 63);
+}
 // value of the lane below (lane 0: 0)
 KS_DEV u32 ks_lane_below(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); } // wave_shr:1
 

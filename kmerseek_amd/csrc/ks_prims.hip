@@ -169,7 +169,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_lookback(const TIn *in, T
                 const u64 is_pre = __ballot(flag == SCAN_FLAG_PRE);
                 const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
                 u64 contrib = tid <= first ? val : 0;
-                for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+                contrib = ks_wave_sum64(contrib);
                 excl += contrib;
                 if (is_pre) done = true; else idx -= 64;
             }

@@ -723,7 +723,7 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
             }
             JN_STAMP_AT(4); // searched
             const u32 wincl = ks_wave_incl_scan(mine);
-            const u32 wtotal = __shfl(wincl, 63, 64); // candidates of this wave
+            const u32 wtotal = (u32)__builtin_amdgcn_readlane((int)wincl, 63); // candidates of this wave (a scalar: v_readlane, no LDS round trip)
             u32 conf = 0;                             // confirmed pairs this lane will write
             u64 rk[JN_WLIST / 64];
             u32 rv[JN_WLIST / 64], okm = 0; // okm: bit it set = slot it of this lane holds a confirmed pair
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(JN_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6
             u64 slot;
             if (seg_mask) { // uniform
                 const u32 cincl = ks_wave_incl_scan(conf);
-                total = __shfl(cincl, 63, 64);
+                total = (u32)__builtin_amdgcn_readlane((int)cincl, 63);
                 JN_STAMP_AT(6); // wave scan
                 unsigned long long wb = 0;
                 if (total) { // uniform per wave
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(JS_THREADS) __attribute__((amdgpu_waves_per_eu(7, 8
                     conf += ok ? 1u : 0u;
                 }
                 const u32 cincl = ks_wave_incl_scan(conf);
-                const u32 total = __shfl(cincl, 63, 64);
+                const u32 total = (u32)__builtin_amdgcn_readlane((int)cincl, 63);
                 if (total) { // uniform per wave
                     unsigned long long wb = 0;
                     if (lane == 0) wb = atomicAdd(cursor, (unsigned long long)total);
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pair_rows_fused(const u64 *keys,
     if (wave == 0) {
         const u32 c = lane < PF_IPT * PF_WAVES ? wcount[lane / PF_WAVES][lane % PF_WAVES] : 0u;
         const u32 incl = ks_wave_incl_scan(c);
-        const u32 total = __shfl(incl, 63, 64);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         if (lane < PF_IPT * PF_WAVES) wcount[lane / PF_WAVES][lane % PF_WAVES] = incl - c;
         if (lane == 0)
             __hip_atomic_store(&status[tile], (tile == 0 ? PF_FLAG_PRE : PF_FLAG_AGG) | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_pair_rows_fused(const u64 *keys,
                 const u64 is_pre = __ballot((v >> 62) == 2);
                 const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
                 u64 contrib = lane <= first ? (v & PF_VAL_MASK) : 0;
-                for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+                contrib = ks_wave_sum64(contrib);
                 excl += contrib;
                 if (is_pre) done = true; else idx -= 64;
             }

@@ -1232,7 +1232,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
                 // lanes at or before the wave's first inclusive prefix contribute
                 const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
                 u64 contrib = lane <= first ? (v & SK_VAL_MASK) : 0;
-                for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+                contrib = ks_wave_sum64(contrib);
                 if (lane == 0) { lb_sum[wave] = contrib; lb_pre[wave] = is_pre ? 1u : 0u; }
                 __syncthreads(); // (the first one also orders everything placed between publication and look-back)
                 bool found = false;
@@ -1729,7 +1729,7 @@ __global__ __launch_bounds__(SK_THREADS) void k_kmerpos_tiles(kp_args A) {
                 const u64 is_pre = __ballot((v >> 62) == 2);
                 const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
                 u64 contrib = tid <= first ? (v & SK_VAL_MASK) : 0;
-                for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+                contrib = ks_wave_sum64(contrib);
                 excl += contrib;
                 if (is_pre) done = true; else idx -= 64;
             }
