@@ -480,7 +480,9 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     if (!A.upper_only && tid < 256) lut_v = A.lut[tid];
     if (tid < 256) bins[tid] = 0;
     if (tid == 256) bins[256] = 0;
-    for (u32 i = tid; i < SK_TILE / 2 + 4; i += SK_THREADS) cnt[i] = 0;
+    static_assert(SK_TILE / 2 == SK_THREADS * 4, "one 16-byte store per thread zeroes the bucket counters");
+    *(uint4 *)&cnt[tid * 4u] = make_uint4(0, 0, 0, 0);
+    if (tid < 4) cnt[SK_TILE / 2 + tid] = 0;
     if (tid < SK_NFLAG) flagbits[tid] = 0;
     __shared__ u32 n_list_s; // CMP: kept windows appended to the list so far
     if (tid == 0) { ext_n = 0; n_list_s = 0; ndup_s = 0; }
@@ -1218,22 +1220,24 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
             u32 spins = 0;
             const long long spin_t0 = wall_clock64();
             for (;;) {
-                const i64 mine = idx - (i64)tid;
-                u64 v = SK_FLAG_PRE; // before tile 0: inclusive prefix 0
-                if (mine >= 0 && wave < SK_LB_WAVES) {
-                    v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while ((v >> 62) == 0 && !ks_spin_expired(spin_t0, spins)) {
-                        __builtin_amdgcn_s_sleep(1);
+                if (wave < SK_LB_WAVES) { // (uniform per wave: the other waves only meet the barrier — they used to reduce a wave of dummies)
+                    const i64 mine = idx - (i64)tid;
+                    u64 v = SK_FLAG_PRE; // before tile 0: inclusive prefix 0
+                    if (mine >= 0) {
                         v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        while ((v >> 62) == 0 && !ks_spin_expired(spin_t0, spins)) {
+                            __builtin_amdgcn_s_sleep(1);
+                            v = __hip_atomic_load(&A.tile_status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
+                    if ((v >> 62) == 0) { atomicOr(&A.ticket[1], 1u); v = SK_FLAG_PRE; } // spin bound expired: flag the error, do not hang
+                    const u64 is_pre = __ballot((v >> 62) == 2);
+                    // lanes at or before the wave's first inclusive prefix contribute
+                    const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
+                    u64 contrib = lane <= first ? (v & SK_VAL_MASK) : 0;
+                    contrib = ks_wave_sum64(contrib);
+                    if (lane == 0) { lb_sum[wave] = contrib; lb_pre[wave] = is_pre ? 1u : 0u; }
                 }
-                if ((v >> 62) == 0) { atomicOr(&A.ticket[1], 1u); v = SK_FLAG_PRE; } // spin bound expired: flag the error, do not hang
-                const u64 is_pre = __ballot((v >> 62) == 2);
-                // lanes at or before the wave's first inclusive prefix contribute
-                const u32 first = is_pre ? (u32)__ffsll((long long)is_pre) - 1u : 64u;
-                u64 contrib = lane <= first ? (v & SK_VAL_MASK) : 0;
-                contrib = ks_wave_sum64(contrib);
-                if (lane == 0) { lb_sum[wave] = contrib; lb_pre[wave] = is_pre ? 1u : 0u; }
                 __syncthreads(); // (the first one also orders everything placed between publication and look-back)
                 bool found = false;
 #pragma unroll
@@ -1626,12 +1630,16 @@ __global__ __launch_bounds__(SK_THREADS) void k_kmerpos_tiles(kp_args A) {
     constexpr u32 NCH = (SK_TILE + SK_PAD) / 16;
     // (tile ids in dispatch order; a launch whose look-back gave up is repeated with ticket ids: 73k tickets on one address
     // were 0.9 ms of queueing for a 1M-protein batch)
-    u32 ticket_v = blockIdx.x;
-    if (A.use_ticket && tid == 0) ticket_v = atomicAdd(&A.ticket[0], 1u);
-    if (tid < 256) lut_s[tid] = A.lut[tid];
-    if (tid == 0) tile_s = ticket_v;
-    __syncthreads();
-    const u32 tile = tile_s;
+    u32 tile = blockIdx.x;
+    if (A.use_ticket) { // (uniform; the repeat launch only)
+        if (tid == 0) tile_s = atomicAdd(&A.ticket[0], 1u);
+        __syncthreads();
+        tile = tile_s;
+    }
+    // the encode table's byte, the tile's residues and its sequence range are requested together (the table byte used to be
+    // stored — i.e. waited for — before anything else was asked for: see k_sketch_tiles)
+    u32 lut_v = 0;
+    if (tid < 256) lut_v = A.lut[tid];
     const u64 g0 = (u64)tile * KP_R;
     uint4 rv = make_uint4(0, 0, 0, 0);
     if (tid < NCH) {
@@ -1654,6 +1662,8 @@ __global__ __launch_bounds__(SK_THREADS) void k_kmerpos_tiles(kp_args A) {
             const u64 v = A.offs[s_first + i + 1] - g0; // ends beyond the tile's first position: never negative
             lend[i] = v > 0x7fffffffULL ? 0x7fffffffu : (u32)v;
         }
+    if (tid < 256) lut_s[tid] = (u8)lut_v;
+    __syncthreads(); // the table
     if (tid < NCH) {
         const u32 in[4] = {rv.x, rv.y, rv.z, rv.w};
         u32 o[4];
