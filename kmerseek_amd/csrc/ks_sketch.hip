@@ -592,6 +592,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
     const bool early = !CMP && A.part_keys != nullptr && B.in_lds;
 #endif
     u32 rkp[SK_E / 2] = {0, 0, 0, 0}; // ranks inside (tile, digit) of my windows, 16 bits each
+    u32 kept_mask = 0, srel_one = 0;  // one-run threads (k >= SK_E): which of my windows were kept; my sequence (relative, capped)
     if (CMP) {
         // ---- phase 2, compacting variant: hash sub-tile by sub-tile, keep the windows under the threshold in an LDS list
         // (hash in tmp, its sequence in the counter words, which are not counting yet), then bucket the compacted list
@@ -711,6 +712,7 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
 #pragma unroll
             for (int i = 0; i < SK_E; i++)
                 bo[i] = ((kpm >> i) & 1u) ? (s24 | (bb[i] << 12) | __builtin_amdgcn_ubfe(rt[i], bb[i] << 4, 16u)) : 0xffffffffu;
+            kept_mask = kpm; srel_one = s24 >> 24;
         } else {
 #pragma unroll
             for (int i = 0; i < SK_E; i++) bo[i] = sk_place_window(A, q0 + i, h[i], q, B, s_end, cnt);
@@ -956,12 +958,19 @@ KS_DEV void sk_tile_body(const sk_args &A, const u32 tile_in) {
         __syncthreads();
     }
     if (fastp) {
+        if (onerun) { // (uniform) the kept mask and the one sequence of the thread are what phase 2 left: nothing to unpack per window
+            rep = kept_mask;
+            srl[0] = srl[1] = srel_one * 0x01010101u;
 #pragma unroll
-        for (int i = 0; i < SK_E; i++) {
-            const bool kept = bo[i] != 0xffffffffu;
-            rep |= (kept ? 1u : 0u) << i;
-            srl[i >> 2] |= (kept ? (bo[i] >> 24) : 0u) << (8 * (i & 3));
-            rk[i] = (rkp[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+            for (int i = 0; i < SK_E; i++) rk[i] = (rkp[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+        } else {
+#pragma unroll
+            for (int i = 0; i < SK_E; i++) {
+                const bool kept = bo[i] != 0xffffffffu;
+                rep |= (kept ? 1u : 0u) << i;
+                srl[i >> 2] |= (kept ? (bo[i] >> 24) : 0u) << (8 * (i & 3));
+                rk[i] = (rkp[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+            }
         }
     } else
     if (any_dup || posts) { // (uniform)
